@@ -1,0 +1,110 @@
+/*
+ * asora_hip.h -- C-ABI of libasora_hip.so, the MI355X (gfx950) implementation of pyC2Ray's
+ * ASORA raytracing path.  Plain pointers and sizes only; no Python, torch or HIP types.
+ *
+ * Every entry point returns 0 on success and a non-zero code on failure;
+ * asora_last_error() then returns a human-readable message (the reference prints HIP/CUDA
+ * errors to stderr and swallows them, src/asora/utils.cu:9-19 + memory.cu:55-57; callers of
+ * this library must check the return code -- the Python shim raises RuntimeError).
+ *
+ * One device per process, process-global state, not re-entrant -- like the reference
+ * (src/asora/memory.cu:28-37).
+ *
+ * Grids are C-ordered double[N*N*N], flat index N*N*i + N*j + k (src/asora/raytracing.cu:38-40).
+ * Source positions are 0-based int32, interleaved x0,y0,z0,x1,... (pyc2ray/utils/sourceutils.py:30).
+ */
+#ifndef ASORA_HIP_H
+#define ASORA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- the six functions of the reference's `libasora` module --------------------------------- */
+
+/* replaces asora::device_init, src/asora/memory.cu:42-86 (Python: python_module.cu:64-74 "iiii").
+ * Selects device mpi_rank % num_gpus and allocates the grid buffers for mesh size N.
+ * num_src_par (the reference's source batch size) is accepted for API compatibility; the number
+ * of sources in flight is decided by the hardware scheduler here (no per-source N^3 buffer). */
+int asora_device_init(int N, int num_src_par, int mpi_rank, int num_gpus);
+
+/* replaces asora::device_close, src/asora/memory.cu:138-150 */
+int asora_device_close(void);
+
+/* replaces asora::density_to_device, src/asora/memory.cu:91-98 (host pointer, N*N*N doubles) */
+int asora_density_to_device(const double *ndens, int N);
+
+/* replaces asora::photo_table_to_device, src/asora/memory.cu:100-115.  Copies num_tau doubles of
+ * each table (as the reference does) and pads the device copy by two replicated entries so the
+ * reference's one-past-the-end read (src/asora/rates.cu:96-100) is defined. */
+int asora_photo_table_to_device(const double *thin_table, const double *thick_table, int num_tau);
+
+/* replaces asora::source_data_to_device, src/asora/memory.cu:117-133 */
+int asora_source_data_to_device(const int32_t *pos, const double *flux, int num_src);
+
+/* replaces asora::do_all_sources_gpu, src/asora/raytracing.cu:98-169 (Python:
+ * python_module.cu:21-59 "dOddOOOiiddi").  All pointers are HOST pointers.  `ndens` is ignored
+ * like in the reference (the copy made by asora_density_to_device is used).  phi_ion and
+ * coldensh_out (N^3 doubles each) are overwritten.  coldensh_out receives the outgoing column
+ * density of the LAST source of the list (the Fortran semantics, raytracing.f90:181; the reference
+ * GPU code returns an unspecified source's grid for num_src > 1), zero outside
+ * the region that source visits. */
+int asora_do_all_sources(double R, double *coldensh_out, double sig, double dr, const double *ndens,
+                         const double *xh_av, double *phi_ion, int num_src, int m1, double minlogtau,
+                         double dlogtau, int num_tau);
+
+/* ---- extensions (no counterpart in the H-only reference module) ------------------------------- */
+
+/* Heating tables + heating-rate output; arithmetic of src/c2ray/photorates.f90:118,124
+ * (the multi-species reference variant exposes the same idea: src/asora_he/python_module_He.cu:22-102). */
+int asora_heat_table_to_device(const double *heat_thin_table, const double *heat_thick_table, int num_tau);
+int asora_do_all_sources_heat(double R, double *coldensh_out, double sig, double dr, const double *ndens,
+                              const double *xh_av, double *phi_ion, double *phi_heat, int num_src, int m1,
+                              double minlogtau, double dlogtau, int num_tau);
+
+/* Device-resident variant: xh_av_dev, phi_ion_dev, phi_heat_dev (nullable), coldensh_out_dev
+ * (nullable) are DEVICE pointers to N^3 doubles; nothing crosses PCIe.  `stream` is a hipStream_t
+ * (NULL = default stream); the call is asynchronous with respect to the host.  This is what
+ * bench.py times and what the multi-GPU driver all-reduces (replaces the host Reduce+Bcast of
+ * pyc2ray/evolve.py:309-317). */
+int asora_do_all_sources_dev(double R, double *coldensh_out_dev, double sig, double dr,
+                             const double *xh_av_dev, double *phi_ion_dev, double *phi_heat_dev,
+                             int num_src, int m1, double minlogtau, double dlogtau, int num_tau,
+                             void *stream);
+
+/* Device-pointer upload of the density (device-to-device copy on `stream`). */
+int asora_density_from_device(const double *ndens_dev, int N, void *stream);
+
+/* replaces asoratest::cinterp_gpu, src/asora/tests.cu:30-59 (Python module libasoratest.cinterp,
+ * python_test_module.cu): for the 4x4x4 block of offsets (i,j,k) in [0,4)^3 from pos0, column density
+ * and path from the short-characteristics interpolation on `dens` (N^3 doubles, used as the
+ * outgoing-column-density grid), sigma = 1.  out = double[4*4*4*2].  `fortran_constants` != 0
+ * uses the float32-rounded sqrt(2), sqrt(3) of the Fortran oracle (what the product path uses),
+ * 0 the truncated decimal constants of src/asora/raytracing.cu:20-21. */
+int asora_test_cinterp(const int32_t pos0[3], const double *dens, int N, double *out, int fortran_constants);
+
+/* Same harness for a cnt^3 block of offsets lo .. lo+cnt-1 per axis (cnt <= 8, negative offsets
+ * allowed, periodic wrap) and any sigma; out = double[cnt*cnt*cnt*2]. */
+int asora_test_cinterp_ex(const int32_t pos0[3], const double *dens, int N, double sigma, int lo, int cnt,
+                          double *out, int fortran_constants);
+
+/* Unit of work of the benchmark metric: cells visited per source (octahedron(q_max) ∩ periodic
+ * box limits) and how many of those lie inside the R sphere; follows
+ * src/asora/raytracing.cu:110,140-141,214-255,320.  Pure host arithmetic. */
+int asora_visit_count(double R, int m1, long long *visits, long long *in_sphere);
+
+/* Duration of the raytracing sweep kernel of the last do_all_sources* call, from HIP events
+ * recorded on the launch stream (synchronises on the stop event). */
+int asora_last_sweep_ms(float *ms);
+
+/* Name of the sweep kernel and its launch geometry of the last call (for profile matching). */
+int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_is_lds);
+
+const char *asora_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASORA_HIP_H */

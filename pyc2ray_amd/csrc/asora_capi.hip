@@ -1,0 +1,463 @@
+// asora_capi.hip -- host side of libasora_hip.so: process-global device state and the
+// extern "C" entry points declared in include/asora_hip.h.
+//
+// State mirrors what the reference keeps in src/asora/memory.cu:28-37 (one device per process),
+// minus the per-source N^3 column-density buffer (cdh_dev[M*N^3], memory.cu:75), which the sector
+// decomposition in asora_kernels.hpp does not need.
+#include "asora_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/asora_hip.h"
+
+namespace {
+
+std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return fail(100 + (int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,   \
+                        __LINE__);                                                                        \
+    } while (0)
+
+struct State {
+    bool init = false;
+    int device = 0;
+    int N = 0;
+    int num_src_par = 0;
+    size_t cells = 0;
+    // grids (N^3 doubles each)
+    double *n_dev = nullptr, *x_dev = nullptr;        // density, ionised fraction (host-API staging)
+    double *nhiA = nullptr, *nhiB = nullptr;          // neutral density, two layouts
+    double *phiA = nullptr, *phiB = nullptr;          // rate accumulators, two layouts
+    double *heatA = nullptr, *heatB = nullptr;        // lazily allocated
+    double *cdhA = nullptr, *cdhB = nullptr;          // lazily allocated
+    double *out0 = nullptr, *out1 = nullptr, *out2 = nullptr;  // merged outputs for the host API (lazy)
+    // tables (padded by 2)
+    double *thin = nullptr, *thick = nullptr, *hthin = nullptr, *hthick = nullptr;
+    int table_len = 0, heat_table_len = 0;
+    // sources
+    int *src_pos = nullptr;
+    double *src_flux = nullptr;
+    int num_src = 0;
+    // staging scratch for planes that do not fit in LDS
+    double *gscratch = nullptr;
+    size_t gscratch_bytes = 0;
+    // timing / launch info
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int last_grid = 0, last_block = 0, last_lds = 0, last_is_lds = 1;
+    int max_lds = 65536;
+    int num_cu = 256;
+};
+
+State S;
+
+void free_ptr(double *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+int alloc_grid(double *&p) {
+    if (p) return 0;
+    HIP_TRY(hipMalloc(&p, S.cells * sizeof(double)));
+    return 0;
+}
+
+int upload_table(double *&dev, const double *host, int n) {
+    // n entries from the host + 2 replicated entries
+    std::vector<double> tmp((size_t)n + 2);
+    std::memcpy(tmp.data(), host, (size_t)n * sizeof(double));
+    tmp[n] = tmp[n + 1] = host[n - 1];
+    if (dev) (void)hipFree(dev);
+    dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, tmp.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(dev, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// q_max exactly as the reference computes it (src/asora/raytracing.cu:110, with its SQRT3 macro)
+int compute_q_max(double R, int m1) {
+    const double SQRT3 = 1.73205080757;
+    return (int)std::ceil(SQRT3 * std::min(R, SQRT3 * m1 / 2.0));
+}
+
+template <bool L, bool H>
+int launch_sweep(const asora::SweepArgs &A, int grid, size_t lds, hipStream_t st) {
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)asora::sweep_kernel<L, H>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((asora::sweep_kernel<L, H>), dim3(grid), dim3(asora::SWEEP_THREADS), lds, st, A);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Common implementation on device pointers.
+int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, const double *xh_dev,
+                        double *phi_out_dev, double *heat_out_dev, int num_src, int m1, double minlogtau,
+                        double dlogtau, int num_tau, hipStream_t st) {
+    if (!S.init) return fail(2, "asora_do_all_sources: device not initialised (call asora_device_init)");
+    if (m1 != S.N) return fail(3, "asora_do_all_sources: m1=%d differs from device_init N=%d", m1, S.N);
+    if (!S.thin || !S.thick) return fail(4, "asora_do_all_sources: photo tables not uploaded");
+    if (num_tau < 1 || num_tau > S.table_len)
+        return fail(5, "asora_do_all_sources: num_tau=%d exceeds the uploaded table length %d", num_tau, S.table_len);
+    if (num_src < 0 || num_src > S.num_src)
+        return fail(6, "asora_do_all_sources: num_src=%d but only %d sources were uploaded", num_src, S.num_src);
+    if (heat_out_dev && (!S.hthin || !S.hthick || num_tau > S.heat_table_len))
+        return fail(7, "asora_do_all_sources_heat: heating tables not uploaded (or shorter than num_tau)");
+    if (!(dr > 0.0) || !(R >= 0.0)) return fail(8, "asora_do_all_sources: need dr > 0 and R >= 0");
+    if (!xh_dev || !phi_out_dev) return fail(9, "asora_do_all_sources: null xh_av / phi_ion pointer");
+
+    const int N = S.N;
+    const size_t bytes = S.cells * sizeof(double);
+    const bool want_heat = heat_out_dev != nullptr;
+    const bool want_cdh = cdh_out_dev != nullptr;
+    if (want_heat) {
+        if (int rc = alloc_grid(S.heatA)) return rc;
+        if (int rc = alloc_grid(S.heatB)) return rc;
+    }
+    if (want_cdh) {
+        if (int rc = alloc_grid(S.cdhA)) return rc;
+        if (int rc = alloc_grid(S.cdhB)) return rc;
+    }
+
+    const dim3 tb(32, 8), tg((N + 31) / 32, (N + 31) / 32, N);
+    hipLaunchKernelGGL(asora::prep_nhi_kernel, tg, tb, 0, st, S.n_dev, xh_dev, S.nhiA, S.nhiB, N);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(S.phiA, 0, bytes, st));
+    HIP_TRY(hipMemsetAsync(S.phiB, 0, bytes, st));
+    if (want_heat) {
+        HIP_TRY(hipMemsetAsync(S.heatA, 0, bytes, st));
+        HIP_TRY(hipMemsetAsync(S.heatB, 0, bytes, st));
+    }
+    if (want_cdh) {
+        HIP_TRY(hipMemsetAsync(S.cdhA, 0, bytes, st));
+        HIP_TRY(hipMemsetAsync(S.cdhB, 0, bytes, st));
+    }
+
+    asora::SweepArgs A;
+    std::memset(&A, 0, sizeof A);
+    A.nhiA = S.nhiA; A.nhiB = S.nhiB; A.phiA = S.phiA; A.phiB = S.phiB;
+    A.heatA = want_heat ? S.heatA : nullptr; A.heatB = want_heat ? S.heatB : nullptr;
+    A.cdhA = want_cdh ? S.cdhA : nullptr; A.cdhB = want_cdh ? S.cdhB : nullptr;
+    A.src_pos = S.src_pos; A.src_flux = S.src_flux;
+    A.thick = S.thick; A.thin = S.thin; A.hthick = S.hthick; A.hthin = S.hthin;
+    A.ntasks = (long long)asora::SECTORS * num_src;
+    A.src_begin = 0;
+    A.cdh_src = want_cdh ? num_src - 1 : -1;
+    A.N = N;
+    A.q_max = compute_q_max(R, N);
+    A.last_r = N / 2 - 1 + N % 2;  // src/asora/raytracing.cu:140-141
+    A.last_l = N / 2;
+    A.num_tau = num_tau;
+    A.R = R; A.sig = sig; A.dr = dr; A.minlogtau = minlogtau; A.dlogtau = dlogtau;
+    // widest plane any sector stages: max_n min(n, lim, q_max - n) + 1, lim = max(last_l, last_r)
+    int wmax = 0;
+    {
+        const int lim = std::max(A.last_l, A.last_r), nmax = std::min(lim, A.q_max);
+        for (int n = 0; n <= nmax; n++) wmax = std::max(wmax, std::min(std::min(n, lim), A.q_max - n));
+    }
+    A.S = wmax + 2;  // b = -1 guard .. wmax
+    A.plane_elems = (wmax + 2) * A.S;
+    const size_t lds = 2 * (size_t)A.plane_elems * sizeof(double);
+    const bool use_lds = lds <= (size_t)S.max_lds;
+
+    S.timed = false;
+    int grid, rc = 0;
+    if (num_src > 0) {
+        if (use_lds) {
+            grid = (int)std::min<long long>(A.ntasks, 0x7fffffffLL);
+        } else {
+            grid = (int)std::min<long long>(A.ntasks, (long long)S.num_cu * 4);
+            const size_t need = (size_t)grid * lds;
+            if (need > S.gscratch_bytes) {
+                if (S.gscratch) (void)hipFree(S.gscratch);
+                S.gscratch = nullptr;
+                S.gscratch_bytes = 0;
+                HIP_TRY(hipMalloc(&S.gscratch, need));
+                S.gscratch_bytes = need;
+            }
+            A.gscratch = S.gscratch;
+        }
+        HIP_TRY(hipEventRecord(S.ev0, st));
+        if (use_lds) rc = want_heat ? launch_sweep<true, true>(A, grid, lds, st) : launch_sweep<true, false>(A, grid, lds, st);
+        else rc = want_heat ? launch_sweep<false, true>(A, grid, 0, st) : launch_sweep<false, false>(A, grid, 0, st);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(S.ev1, st));
+        S.timed = true;
+        S.last_grid = grid; S.last_block = asora::SWEEP_THREADS; S.last_lds = use_lds ? (int)lds : 0;
+        S.last_is_lds = use_lds ? 1 : 0;
+    }
+
+    hipLaunchKernelGGL(asora::finalize_kernel, tg, tb, 0, st, S.phiA, S.phiB, phi_out_dev, N);
+    HIP_TRY(hipGetLastError());
+    if (want_heat) {
+        hipLaunchKernelGGL(asora::finalize_kernel, tg, tb, 0, st, S.heatA, S.heatB, heat_out_dev, N);
+        HIP_TRY(hipGetLastError());
+    }
+    if (want_cdh) {
+        hipLaunchKernelGGL(asora::finalize_kernel, tg, tb, 0, st, S.cdhA, S.cdhB, cdh_out_dev, N);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int do_all_sources_host(double R, double *coldensh_out, double sig, double dr, const double *xh_av,
+                        double *phi_ion, double *phi_heat, int num_src, int m1, double minlogtau,
+                        double dlogtau, int num_tau) {
+    if (!S.init) return fail(2, "asora_do_all_sources: device not initialised (call asora_device_init)");
+    if (m1 != S.N) return fail(3, "asora_do_all_sources: m1=%d differs from device_init N=%d", m1, S.N);
+    if (!xh_av || !phi_ion) return fail(9, "asora_do_all_sources: null xh_av / phi_ion pointer");
+    const size_t bytes = S.cells * sizeof(double);
+    if (int rc = alloc_grid(S.out0)) return rc;
+    if (coldensh_out) if (int rc = alloc_grid(S.out1)) return rc;
+    if (phi_heat) if (int rc = alloc_grid(S.out2)) return rc;
+    HIP_TRY(hipMemcpy(S.x_dev, xh_av, bytes, hipMemcpyHostToDevice));  // src/asora/raytracing.cu:130
+    int rc = do_all_sources_impl(R, coldensh_out ? S.out1 : nullptr, sig, dr, S.x_dev, S.out0,
+                                 phi_heat ? S.out2 : nullptr, num_src, m1, minlogtau, dlogtau, num_tau, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(phi_ion, S.out0, bytes, hipMemcpyDeviceToHost));  // raytracing.cu:163-166
+    if (coldensh_out) HIP_TRY(hipMemcpy(coldensh_out, S.out1, bytes, hipMemcpyDeviceToHost));
+    if (phi_heat) HIP_TRY(hipMemcpy(phi_heat, S.out2, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *asora_last_error(void) { return g_err.c_str(); }
+
+int asora_device_init(int N, int num_src_par, int mpi_rank, int num_gpus) {
+    if (N < 2) return fail(1, "asora_device_init: mesh size N=%d must be >= 2", N);
+    if (num_gpus < 1) return fail(1, "asora_device_init: num_gpus=%d must be >= 1", num_gpus);
+    if (S.init) asora_device_close();
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(1, "asora_device_init: no HIP device visible");
+    const int dev = ((mpi_rank % num_gpus) + num_gpus) % num_gpus;  // src/asora/memory.cu:46
+    if (dev >= ndev) return fail(1, "asora_device_init: device %d requested but only %d visible", dev, ndev);
+    HIP_TRY(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    S.device = dev;
+    S.N = N;
+    S.num_src_par = num_src_par;
+    S.cells = (size_t)N * N * N;
+    S.num_cu = prop.multiProcessorCount;
+    // leave a little LDS head-room; a workgroup may use up to the whole 160 KiB of a CU
+    S.max_lds = (int)std::min<size_t>(prop.sharedMemPerBlock > 0 ? prop.sharedMemPerBlock : 65536, 160 * 1024);
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
+            S.max_lds = std::max(S.max_lds, std::min(v, 160 * 1024));
+    }
+    double **grids[] = {&S.n_dev, &S.x_dev, &S.nhiA, &S.nhiB, &S.phiA, &S.phiB};
+    for (double **g : grids) {
+        hipError_t e = hipMalloc(g, S.cells * sizeof(double));
+        if (e != hipSuccess) {
+            for (double **h : grids) free_ptr(*h);
+            return fail(100 + (int)e, "asora_device_init: hipMalloc of %zu bytes failed: %s", S.cells * sizeof(double),
+                        hipGetErrorString(e));
+        }
+    }
+    HIP_TRY(hipEventCreate(&S.ev0));
+    HIP_TRY(hipEventCreate(&S.ev1));
+    S.init = true;
+    return 0;
+}
+
+int asora_device_close(void) {
+    if (!S.init) return fail(2, "asora_device_close: device not initialised");
+    (void)hipDeviceSynchronize();
+    double **grids[] = {&S.n_dev, &S.x_dev, &S.nhiA, &S.nhiB, &S.phiA, &S.phiB, &S.heatA, &S.heatB, &S.cdhA,
+                        &S.cdhB, &S.out0, &S.out1, &S.out2, &S.thin, &S.thick, &S.hthin, &S.hthick,
+                        &S.src_flux, &S.gscratch};
+    for (double **g : grids) free_ptr(*g);
+    if (S.src_pos) (void)hipFree(S.src_pos);
+    S.src_pos = nullptr;
+    if (S.ev0) (void)hipEventDestroy(S.ev0);
+    if (S.ev1) (void)hipEventDestroy(S.ev1);
+    S = State();
+    return 0;
+}
+
+int asora_density_to_device(const double *ndens, int N) {
+    if (!S.init) return fail(2, "asora_density_to_device: device not initialised");
+    if (N != S.N) return fail(3, "asora_density_to_device: N=%d differs from device_init N=%d", N, S.N);
+    if (!ndens) return fail(9, "asora_density_to_device: null pointer");
+    HIP_TRY(hipMemcpy(S.n_dev, ndens, S.cells * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int asora_density_from_device(const double *ndens_dev, int N, void *stream) {
+    if (!S.init) return fail(2, "asora_density_from_device: device not initialised");
+    if (N != S.N) return fail(3, "asora_density_from_device: N=%d differs from device_init N=%d", N, S.N);
+    if (!ndens_dev) return fail(9, "asora_density_from_device: null pointer");
+    HIP_TRY(hipMemcpyAsync(S.n_dev, ndens_dev, S.cells * sizeof(double), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+    return 0;
+}
+
+int asora_photo_table_to_device(const double *thin_table, const double *thick_table, int num_tau) {
+    if (!S.init) return fail(2, "asora_photo_table_to_device: device not initialised");
+    if (num_tau < 1 || !thin_table || !thick_table) return fail(9, "asora_photo_table_to_device: bad arguments");
+    if (int rc = upload_table(S.thin, thin_table, num_tau)) return rc;
+    if (int rc = upload_table(S.thick, thick_table, num_tau)) return rc;
+    S.table_len = num_tau;
+    return 0;
+}
+
+int asora_heat_table_to_device(const double *heat_thin_table, const double *heat_thick_table, int num_tau) {
+    if (!S.init) return fail(2, "asora_heat_table_to_device: device not initialised");
+    if (num_tau < 1 || !heat_thin_table || !heat_thick_table) return fail(9, "asora_heat_table_to_device: bad arguments");
+    if (int rc = upload_table(S.hthin, heat_thin_table, num_tau)) return rc;
+    if (int rc = upload_table(S.hthick, heat_thick_table, num_tau)) return rc;
+    S.heat_table_len = num_tau;
+    return 0;
+}
+
+int asora_source_data_to_device(const int32_t *pos, const double *flux, int num_src) {
+    if (!S.init) return fail(2, "asora_source_data_to_device: device not initialised");
+    if (num_src < 0 || (num_src > 0 && (!pos || !flux))) return fail(9, "asora_source_data_to_device: bad arguments");
+    for (int i = 0; i < 3 * num_src; i++)
+        if (pos[i] < 0 || pos[i] >= S.N)
+            return fail(10, "asora_source_data_to_device: source %d coordinate %d = %d outside [0, %d)", i / 3, i % 3,
+                        pos[i], S.N);
+    // the reference re-allocates on every call and never frees (memory.cu:121,127); we do free
+    if (S.src_pos) (void)hipFree(S.src_pos);
+    if (S.src_flux) (void)hipFree(S.src_flux);
+    S.src_pos = nullptr;
+    S.src_flux = nullptr;
+    S.num_src = 0;
+    const size_t n = (size_t)std::max(num_src, 1);
+    HIP_TRY(hipMalloc(&S.src_pos, 3 * n * sizeof(int)));
+    HIP_TRY(hipMalloc(&S.src_flux, n * sizeof(double)));
+    if (num_src > 0) {
+        HIP_TRY(hipMemcpy(S.src_pos, pos, 3 * (size_t)num_src * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(S.src_flux, flux, (size_t)num_src * sizeof(double), hipMemcpyHostToDevice));
+    }
+    S.num_src = num_src;
+    return 0;
+}
+
+int asora_do_all_sources(double R, double *coldensh_out, double sig, double dr, const double *ndens,
+                         const double *xh_av, double *phi_ion, int num_src, int m1, double minlogtau,
+                         double dlogtau, int num_tau) {
+    (void)ndens;  // ignored, like the reference (src/asora/raytracing.cu:127-129)
+    return do_all_sources_host(R, coldensh_out, sig, dr, xh_av, phi_ion, nullptr, num_src, m1, minlogtau, dlogtau,
+                               num_tau);
+}
+
+int asora_do_all_sources_heat(double R, double *coldensh_out, double sig, double dr, const double *ndens,
+                              const double *xh_av, double *phi_ion, double *phi_heat, int num_src, int m1,
+                              double minlogtau, double dlogtau, int num_tau) {
+    (void)ndens;
+    if (!phi_heat) return fail(9, "asora_do_all_sources_heat: null phi_heat pointer");
+    return do_all_sources_host(R, coldensh_out, sig, dr, xh_av, phi_ion, phi_heat, num_src, m1, minlogtau, dlogtau,
+                               num_tau);
+}
+
+int asora_do_all_sources_dev(double R, double *coldensh_out_dev, double sig, double dr, const double *xh_av_dev,
+                             double *phi_ion_dev, double *phi_heat_dev, int num_src, int m1, double minlogtau,
+                             double dlogtau, int num_tau, void *stream) {
+    return do_all_sources_impl(R, coldensh_out_dev, sig, dr, xh_av_dev, phi_ion_dev, phi_heat_dev, num_src, m1,
+                               minlogtau, dlogtau, num_tau, (hipStream_t)stream);
+}
+
+int asora_test_cinterp_ex(const int32_t pos0[3], const double *dens, int N, double sigma, int lo, int cnt,
+                          double *out, int fortran_constants);
+
+int asora_test_cinterp(const int32_t pos0[3], const double *dens, int N, double *out, int fortran_constants) {
+    return asora_test_cinterp_ex(pos0, dens, N, 1.0, 0, 4, out, fortran_constants);
+}
+
+int asora_test_cinterp_ex(const int32_t pos0[3], const double *dens, int N, double sigma, int lo, int cnt,
+                          double *out, int fortran_constants) {
+    if (!pos0 || !dens || !out || N < 2 || cnt < 1 || cnt > 8) return fail(9, "asora_test_cinterp: bad arguments");
+    const size_t nb = (size_t)N * N * N * sizeof(double), ob = (size_t)cnt * cnt * cnt * 2 * sizeof(double);
+    double *d_dens = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_dens, nb));
+    hipError_t e = hipMalloc(&d_out, ob);
+    if (e != hipSuccess) {
+        (void)hipFree(d_dens);
+        return fail(100 + (int)e, "asora_test_cinterp: hipMalloc failed");  // reference: MemoryError
+    }
+    int rc = 0;
+    do {
+        if ((e = hipMemcpy(d_dens, dens, nb, hipMemcpyHostToDevice)) != hipSuccess) break;
+        hipLaunchKernelGGL(asora::cinterp_test_kernel, dim3(1), dim3(cnt, cnt, cnt), 0, nullptr, d_out, d_dens,
+                           pos0[0], pos0[1], pos0[2], N, sigma, lo, fortran_constants);
+        if ((e = hipGetLastError()) != hipSuccess) break;
+        if ((e = hipMemcpy(out, d_out, ob, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    } while (0);
+    if (e != hipSuccess) rc = fail(100 + (int)e, "asora_test_cinterp: %s", hipGetErrorString(e));
+    (void)hipFree(d_dens);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int asora_visit_count(double R, int m1, long long *visits, long long *in_sphere) {
+    if (m1 < 2 || !visits || !in_sphere) return fail(9, "asora_visit_count: bad arguments");
+    const int q_max = compute_q_max(R, m1);
+    const int last_r = m1 / 2 - 1 + m1 % 2, last_l = -(m1 / 2);
+    long long v = 0, s = 0;
+    // rows of constant (i, j): k ranges over |k| <= q_max - |i| - |j| clipped to the box
+    for (int i = last_l; i <= last_r; i++)
+        for (int j = last_l; j <= last_r; j++) {
+            const int rem = q_max - std::abs(i) - std::abs(j);
+            if (rem < 0) continue;
+            const int klo = std::max(last_l, -rem), khi = std::min(last_r, rem);
+            v += khi - klo + 1;
+            const double r2 = R * R - (double)i * i - (double)j * j;
+            if (r2 < 0) continue;
+            const int kr = (int)std::floor(std::sqrt(r2));
+            int a = std::max(klo, -kr), b = std::min(khi, kr);
+            // fix rounding of sqrt on the boundary
+            while (a - 1 >= klo && (double)(a - 1) * (a - 1) <= r2) a--;
+            while (b + 1 <= khi && (double)(b + 1) * (b + 1) <= r2) b++;
+            while (a <= b && (double)a * a > r2) a++;
+            while (b >= a && (double)b * b > r2) b--;
+            if (b >= a) s += b - a + 1;
+        }
+    *visits = v;
+    *in_sphere = s;
+    return 0;
+}
+
+int asora_last_sweep_ms(float *ms) {
+    if (!ms) return fail(9, "asora_last_sweep_ms: null pointer");
+    if (!S.init || !S.timed) return fail(11, "asora_last_sweep_ms: no sweep has been timed");
+    HIP_TRY(hipEventSynchronize(S.ev1));
+    HIP_TRY(hipEventElapsedTime(ms, S.ev0, S.ev1));
+    return 0;
+}
+
+int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_is_lds) {
+    if (grid) *grid = S.last_grid;
+    if (block) *block = S.last_block;
+    if (lds_bytes) *lds_bytes = S.last_lds;
+    if (staging_is_lds) *staging_is_lds = S.last_is_lds;
+    return 0;
+}
+
+}  // extern "C"

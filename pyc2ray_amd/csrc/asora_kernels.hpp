@@ -1,0 +1,374 @@
+// asora_kernels.hpp -- device code of the MI355X (gfx950) ASORA raytracer.
+//
+// WHAT IS COMPUTED is fixed by the reference: for every source, every cell of
+// octahedron(q_max) ∩ periodic-box limits (src/asora/raytracing.cu:110,140-141,214-255) gets
+//   cdh_in  = short-characteristics interpolation of the outgoing column density of its four
+//             upwind neighbours (src/c2ray/raytracing.f90:576-815 == src/asora/raytracing.cu:354-439)
+//   cdh_out = cdh_in + nHI * path                                  (raytracing.f90:488)
+//   Gamma   = table rates(cdh_in, cdh_out) / nHI, added to phi_ion  (raytracing.f90:495-537,
+//             src/c2ray/photorates.f90:62-149), unless cdh_in > 2e30f or dist^2/dr^2 > R^2.
+// The ARITHMETIC follows the Fortran oracle operation for operation (float32-rounded sqrt2/sqrt3,
+// 1e-7f threshold, tau_in for the thin lookup, no FMA contraction -- SURVEY.md 3.4).
+//
+// HOW it is computed is NOT the reference's design (one block per source, Manhattan shells,
+// an N^3 column-density grid per in-flight source in global memory, a barrier per shell):
+//
+//   * A cell reads only cells of the plane one step closer to the source along its DOMINANT axis.
+//     With the reference's tie rule (z before y before x) the upwind stencil of a closed pyramid
+//     {|d_p| >= |d_u|, |d_p| >= |d_v|} never leaves that pyramid with non-zero weight, and inside a
+//     pyramid the four sign quadrants (su, sv) are closed too.  So one source splits into
+//     6 pyramids x 4 quadrants = 24 independent SECTORS.  A sector is a march over planes
+//     n = 1..nmax; plane n holds cells (a, b), 0 <= a, b <= n, and cell (a, b) reads
+//     (a-1,b-1), (a,b-1), (a-1,b), (a,b) of plane n-1.
+//   * One 256-thread workgroup owns one (source, sector) task.  Two planes of column densities
+//     live in LDS (double buffer, one barrier per plane); nothing but the final rates ever goes
+//     to HBM.  Memory per task is O(n^2), not O(N^3), so the number of sources in flight is set
+//     by occupancy, not by a batch-size parameter.
+//   * Cells on sector boundaries (a = 0, b = 0, a = n, b = n) are computed by 2-3 sectors (they
+//     are needed as upwind values) but OWNED -- i.e. produce rates / cdh output -- by exactly one,
+//     chosen with the reference's own rules (tie order z,y,x; sign(0) = +1).
+//   * In-plane coordinate b runs along the memory-contiguous axis: x- and y-sectors read the
+//     neutral density and add rates in the [i][j][k] layout, z-sectors in a transposed [i][k][j]
+//     copy.  A wavefront therefore touches whole rows (coalesced loads and coalesced f64 atomics).
+//     The two rate grids are merged by finalize_kernel.
+//   * nHI = ndens * (1 - xh) is formed once per call (prep_nhi_kernel), so a visit loads 8 B.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace asora {
+
+constexpr int SWEEP_THREADS = 256;
+constexpr int SECTORS = 24;
+constexpr double FOURPI = 4.0 * 3.14159265358979323846264338;  // raytracing.f90:47,457
+constexpr double SQRT3_F32 = 1.7320507764816284;                // (double)sqrtf(3.0f), raytracing.f90:608
+constexpr double SQRT2_F32 = 1.4142135381698608;                // (double)sqrtf(2.0f), raytracing.f90:609
+constexpr double SQRT3_CUDA = 1.73205080757;                    // src/asora/raytracing.cu:20-21
+constexpr double SQRT2_CUDA = 1.41421356237;
+
+struct SweepArgs {
+    const double *nhiA;  // nHI, [i][j][k]
+    const double *nhiB;  // nHI, [i][k][j]
+    double *phiA, *phiB;    // rate accumulators in the two layouts
+    double *heatA, *heatB;  // heating accumulators (HEAT only)
+    double *cdhA, *cdhB;    // column density of source `cdh_src` in the two layouts (may be null)
+    const int *src_pos;     // 0-based, interleaved
+    const double *src_flux;
+    const double *thick, *thin, *hthick, *hthin;  // padded tables
+    double *gscratch;       // global staging (when LDS is too small), 2*plane_elems per block
+    long long ntasks;       // 24 * number of sources of this launch
+    int src_begin;          // first source of this launch
+    int cdh_src;            // source whose column density is exported (-1: none)
+    int N, q_max, last_l, last_r;  // last_l > 0: lowest offset is -last_l
+    int S;                  // row stride of a staged plane (max width + 1 guard)
+    int plane_elems;        // rows * S
+    int num_tau;
+    double R, sig, dr, minlogtau, dlogtau;
+};
+
+struct Lookup {
+    int i0;
+    double residual;
+};
+
+// photorates.f90:139-143 (index part of photo_lookuptable); log10 is the device library's.
+__device__ __forceinline__ Lookup table_index(double tau, double minlogtau, double dlogtau, int num_tau) {
+    double logtau = log10(fmax(1.0e-20, tau));
+    double real_i = fmin((double)num_tau, fmax(0.0, 1.0 + (logtau - minlogtau) / dlogtau));
+    Lookup L;
+    L.i0 = (int)real_i;
+    L.residual = real_i - (double)L.i0;
+    return L;
+}
+
+// photorates.f90:146; the table is padded so that i0 + 1 is always readable.
+__device__ __forceinline__ double table_eval(const double *__restrict__ t, Lookup L) {
+    double t0 = t[L.i0], t1 = t[L.i0 + 1];
+    return t0 + L.residual * (t1 - t0);
+}
+
+// photorates.f90:62-125 followed by the division by nHI of raytracing.f90:531-532
+template <bool HEAT>
+__device__ __forceinline__ void cell_rates(const SweepArgs &A, double flux, double cdh_in, double cdh_out,
+                                           double vol_ph, double nHI, double &phi, double &heat) {
+    const double tau_photo_limit = (double)1.0e-7f;
+    double tau_in = cdh_in * A.sig;
+    double tau_out = cdh_out * A.sig;
+    double prefact = flux / vol_ph;
+    Lookup Lin = table_index(tau_in, A.minlogtau, A.dlogtau, A.num_tau);
+    double phi_in = prefact * table_eval(A.thick, Lin);
+    if (fabs(tau_out - tau_in) > tau_photo_limit) {
+        Lookup Lout = table_index(tau_out, A.minlogtau, A.dlogtau, A.num_tau);
+        double phi_out = prefact * table_eval(A.thick, Lout);
+        phi = phi_in - phi_out;
+        if (HEAT) heat = prefact * (table_eval(A.hthick, Lin) - table_eval(A.hthick, Lout));
+    } else {
+        phi = prefact * (tau_out - tau_in) * table_eval(A.thin, Lin);
+        if (HEAT) heat = prefact * (tau_out - tau_in) * table_eval(A.hthin, Lin);
+    }
+    phi = phi / nHI;
+    if (HEAT) heat = heat / nHI;
+}
+
+// raytracing.f90:807-813
+__device__ __forceinline__ double weightf(double cd, double sig) { return 1.0 / fmax(0.6, cd * sig); }
+
+// The interpolation of raytracing.f90:662-710 / 715-758 / 764-800 in sector coordinates.
+//   n >= 1 : distance along the dominant axis;  a, b >= 0 : in-plane distances (u, v axes)
+//   su, sv : signs of the in-plane offsets;  u1, v1 : 1-BASED source coordinates on those axes
+//            (the oracle's crossing point xc = alam*di + real(i0) carries the absolute position)
+//   c1..c4 : outgoing column densities of (a-1,b-1), (a,b-1), (a-1,b), (a,b) in plane n-1
+__device__ __forceinline__ void cinterp_sector(int n, int a, int b, int su, int sv, int u1, int v1, double c1,
+                                               double c2, double c3, double c4, double sig, double sqrt3,
+                                               double sqrt2, double &cdensi, double &path) {
+    double dn = (double)n;
+    double alam = (dn - 0.5) / dn;
+    double dU = (double)(su * a), dV = (double)(sv * b);
+    double uc = alam * dU + (double)u1;
+    double vc = alam * dV + (double)v1;
+    double uh = (double)(u1 + su * (a - 1)) + 0.5 * (double)su;
+    double vh = (double)(v1 + sv * (b - 1)) + 0.5 * (double)sv;
+    double du = 2.0 * fabs(uc - uh);
+    double dv = 2.0 * fabs(vc - vh);
+    double s1 = (1. - du) * (1. - dv);
+    double s2 = (1. - dv) * du;
+    double s3 = (1. - du) * dv;
+    double s4 = du * dv;
+    double w1 = s1 * weightf(c1, sig);
+    double w2 = s2 * weightf(c2, sig);
+    double w3 = s3 * weightf(c3, sig);
+    double w4 = s4 * weightf(c4, sig);
+    cdensi = (c1 * w1 + c2 * w2 + c3 * w3 + c4 * w4) / (w1 + w2 + w3 + w4);
+    if (n == 1 && (a == 1 || b == 1)) {
+        if (a == 1 && b == 1) cdensi = sqrt3 * cdensi;
+        else cdensi = sqrt2 * cdensi;
+    }
+    path = sqrt((double)(a * a + b * b) / (dn * dn) + 1.0);
+}
+
+__device__ __forceinline__ int wrap(int x, int N) {
+    x += (x < 0) ? N : 0;
+    x -= (x >= N) ? N : 0;
+    return x;
+}
+
+template <bool LDS_STAGE>
+struct Stage {
+    double *g;
+    __device__ __forceinline__ double ld(int off) const;
+    __device__ __forceinline__ void st(int off, double v) const;
+};
+extern __shared__ double asora_smem[];
+template <>
+__device__ __forceinline__ double Stage<true>::ld(int off) const { return asora_smem[off]; }
+template <>
+__device__ __forceinline__ void Stage<true>::st(int off, double v) const { asora_smem[off] = v; }
+template <>
+__device__ __forceinline__ double Stage<false>::ld(int off) const { return g[off]; }
+template <>
+__device__ __forceinline__ void Stage<false>::st(int off, double v) const { g[off] = v; }
+
+// ------------------------------------------------------------------------------------------
+// The sweep: one workgroup per (source, sector) task (grid-stride over tasks).
+// ------------------------------------------------------------------------------------------
+template <bool LDS_STAGE, bool HEAT>
+__global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
+    Stage<LDS_STAGE> stg;
+    stg.g = LDS_STAGE ? nullptr : A.gscratch + (size_t)blockIdx.x * 2 * (size_t)A.plane_elems;
+    const int tid = threadIdx.x;
+    const int S = A.S;
+    const int plane = A.plane_elems;
+    const int N = A.N;
+    const size_t N2 = (size_t)N * N;
+    const double max_coldensh = (double)2e30f;  // raytracing.f90:368
+    const double R2 = A.R * A.R;
+    const double dr2 = A.dr * A.dr;
+
+    for (long long task = blockIdx.x; task < A.ntasks; task += gridDim.x) {
+        const int s = (int)(task / SECTORS);
+        const int t = (int)(task - (long long)s * SECTORS);
+        const int src = A.src_begin + s;
+        const int axis = t >> 3;  // 0: z-dominant, 1: y-dominant, 2: x-dominant
+        const int sp = (t & 4) ? -1 : 1;
+        const int su = (t & 2) ? -1 : 1;
+        const int sv = (t & 1) ? -1 : 1;
+        const int i0 = A.src_pos[3 * src + 0], j0 = A.src_pos[3 * src + 1], k0 = A.src_pos[3 * src + 2];
+        const double flux = A.src_flux[src];
+        int p0, u0, v0;
+        if (axis == 0) { p0 = k0; u0 = i0; v0 = j0; }
+        else if (axis == 1) { p0 = j0; u0 = i0; v0 = k0; }
+        else { p0 = i0; u0 = j0; v0 = k0; }
+        const double *__restrict__ nhi = (axis == 0) ? A.nhiB : A.nhiA;
+        double *__restrict__ phi = (axis == 0) ? A.phiB : A.phiA;
+        double *__restrict__ heat = (axis == 0) ? A.heatB : A.heatA;
+        double *__restrict__ cdh = (axis == 0) ? A.cdhB : A.cdhA;
+        const bool write_cdh = (src == A.cdh_src) && (cdh != nullptr);
+        const int limp = sp > 0 ? A.last_r : A.last_l;
+        const int limu = su > 0 ? A.last_r : A.last_l;
+        const int limv = sv > 0 ? A.last_r : A.last_l;
+        const int nmax = min(limp, A.q_max);
+        // index = pw*strideP + uw*strideU + vw
+        const size_t strideP = (axis == 2) ? N2 : (size_t)N;
+        const size_t strideU = (axis == 2) ? (size_t)N : N2;
+
+        // guard cells and never-written cells must read as 0 (their weights are 0 or O(eps))
+        for (int i = tid; i < 2 * plane; i += SWEEP_THREADS) stg.st(i, 0.0);
+        __syncthreads();
+
+        if (tid == 0) {
+            // source cell, raytracing.f90:430-439
+            size_t g0 = (size_t)p0 * strideP + (size_t)u0 * strideU + (size_t)v0;
+            double nHI = nhi[g0];
+            double path = 0.5 * A.dr;
+            double cdo = 0.0 + nHI * path;
+            stg.st(S + 1, cdo);
+            if (t == 0) {
+                double vol_ph = A.dr * A.dr * A.dr;
+                double ph, ht = 0.0;
+                cell_rates<HEAT>(A, flux, 0.0, cdo, vol_ph, nHI, ph, ht);
+                unsafeAtomicAdd(phi + g0, ph);
+                if (HEAT) unsafeAtomicAdd(heat + g0, ht);
+                if (write_cdh) cdh[g0] = cdo;
+            }
+        }
+        __syncthreads();
+
+        for (int n = 1; n <= nmax; n++) {
+            const int cur = (n & 1) * plane, prev = ((n - 1) & 1) * plane;
+            const int cut = A.q_max - n;  // a + b <= cut
+            const int Hn = min(min(n, limu), cut) + 1;
+            const int Wn = min(min(n, limv), cut) + 1;
+            const int ncell = Hn * Wn;
+            const float invW = 1.0f / (float)Wn;
+            const int pw = wrap(p0 + sp * n, N);
+            const size_t baseP = (size_t)pw * strideP;
+            const double P2 = (A.dr * (double)n) * (A.dr * (double)n);
+            for (int idx = tid; idx < ncell; idx += SWEEP_THREADS) {
+                const int a = (int)(((float)idx + 0.5f) * invW);
+                const int b = idx - a * Wn;
+                if (a + b > cut) continue;
+                const int uw = wrap(u0 + su * a, N), vw = wrap(v0 + sv * b, N);
+                const size_t g = baseP + (size_t)uw * strideU + (size_t)vw;
+                const double nHI = nhi[g];
+                const double c1 = stg.ld(prev + a * S + b);
+                const double c2 = stg.ld(prev + (a + 1) * S + b);
+                const double c3 = stg.ld(prev + a * S + b + 1);
+                const double c4 = stg.ld(prev + (a + 1) * S + b + 1);
+                double cdh_in, path;
+                cinterp_sector(n, a, b, su, sv, u0 + 1, v0 + 1, c1, c2, c3, c4, A.sig, SQRT3_F32, SQRT2_F32,
+                               cdh_in, path);
+                path = path * A.dr;
+                // raytracing.f90:448-451: dist2 = xs*xs + ys*ys + zs*zs in x, y, z order
+                const double U2 = (A.dr * (double)a) * (A.dr * (double)a);
+                const double V2 = (A.dr * (double)b) * (A.dr * (double)b);
+                const double dist2 = (axis == 0) ? (U2 + V2) + P2 : (U2 + P2) + V2;
+                const double vol_ph = dist2 * path * FOURPI;
+                const bool stop = (dist2 / dr2 > R2) || (cdh_in > max_coldensh);
+                const double cdo = cdh_in + nHI * path;
+                stg.st(cur + (a + 1) * S + b + 1, cdo);
+                // ownership: reference tie order (z, y, x) and sign(0) = +1
+                const bool ghost = (su < 0 && a == 0) || (sv < 0 && b == 0) || (axis >= 1 && b == n) ||
+                                   (axis == 2 && a == n);
+                if (!ghost) {
+                    if (write_cdh) cdh[g] = cdo;
+                    if (!stop) {
+                        double ph, ht = 0.0;
+                        cell_rates<HEAT>(A, flux, cdh_in, cdo, vol_ph, nHI, ph, ht);
+                        unsafeAtomicAdd(phi + g, ph);
+                        if (HEAT) unsafeAtomicAdd(heat + g, ht);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// nhiA[i][j][k] = ndens*(1-xh) and its [i][k][j] transpose (raytracing.f90:421-422 arithmetic).
+// grid (N/32, N/32, N), block (32, 8).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_nhi_kernel(const double *__restrict__ ndens,
+                                                       const double *__restrict__ xh, double *__restrict__ nhiA,
+                                                       double *__restrict__ nhiB, int N) {
+    __shared__ double tile[32][33];
+    const size_t slab = (size_t)blockIdx.z * N * N;
+    const int k = blockIdx.x * 32 + threadIdx.x;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int j = blockIdx.y * 32 + r;
+        if (j < N && k < N) {
+            const size_t id = slab + (size_t)j * N + k;
+            const double v = ndens[id] * (1.0 - xh[id]);
+            nhiA[id] = v;
+            tile[r][threadIdx.x] = v;
+        }
+    }
+    __syncthreads();
+    const int j2 = blockIdx.y * 32 + threadIdx.x;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int k2 = blockIdx.x * 32 + r;
+        if (j2 < N && k2 < N) nhiB[slab + (size_t)k2 * N + j2] = tile[threadIdx.x][r];
+    }
+}
+
+// out[i][j][k] = A[i][j][k] + B[i][k][j]  (merge of the two accumulation layouts)
+__global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict__ A, const double *__restrict__ B,
+                                                       double *__restrict__ out, int N) {
+    __shared__ double tile[32][33];
+    const size_t slab = (size_t)blockIdx.z * N * N;
+    // read B[i][k][j] with j contiguous
+    const int j = blockIdx.y * 32 + threadIdx.x;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int k = blockIdx.x * 32 + r;
+        if (j < N && k < N) tile[r][threadIdx.x] = B[slab + (size_t)k * N + j];
+    }
+    __syncthreads();
+    const int k2 = blockIdx.x * 32 + threadIdx.x;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int j2 = blockIdx.y * 32 + r;
+        if (j2 < N && k2 < N) {
+            const size_t id = slab + (size_t)j2 * N + k2;
+            out[id] = A[id] + tile[threadIdx.x][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Known-answer harness (replaces cinterp_gpu_kernel, src/asora/tests.cu:12-25): one thread per
+// offset of a 4x4x4 block, gathers from a global grid and calls the SAME cinterp_sector.
+// ------------------------------------------------------------------------------------------
+__global__ void cinterp_test_kernel(double *out, const double *dens, int i0, int j0, int k0, int N,
+                                    double sigma, int lo, int fortran_constants) {
+    const int di = lo + (int)threadIdx.x, dj = lo + (int)threadIdx.y, dk = lo + (int)threadIdx.z;
+    const int ai = abs(di), aj = abs(dj), ak = abs(dk);
+    const int si = di >= 0 ? 1 : -1, sj = dj >= 0 ? 1 : -1, sk = dk >= 0 ? 1 : -1;
+    const size_t N2 = (size_t)N * N;
+    auto at = [&](int i, int j, int k) {
+        return dens[(size_t)wrap(i % N, N) * N2 + (size_t)wrap(j % N, N) * N + wrap(k % N, N)];
+    };
+    const int i = i0 + di, j = j0 + dj, k = k0 + dk;
+    double c1, c2, c3, c4, cd, path;
+    int n, a, b, su, sv, u1, v1;
+    if (ak >= aj && ak >= ai) {
+        n = ak; a = ai; b = aj; su = si; sv = sj; u1 = i0 + 1; v1 = j0 + 1;
+        c1 = at(i - si, j - sj, k - sk); c2 = at(i, j - sj, k - sk); c3 = at(i - si, j, k - sk); c4 = at(i, j, k - sk);
+    } else if (aj >= ai && aj >= ak) {
+        n = aj; a = ai; b = ak; su = si; sv = sk; u1 = i0 + 1; v1 = k0 + 1;
+        c1 = at(i - si, j - sj, k - sk); c2 = at(i, j - sj, k - sk); c3 = at(i - si, j - sj, k); c4 = at(i, j - sj, k);
+    } else {
+        n = ai; a = aj; b = ak; su = sj; sv = sk; u1 = j0 + 1; v1 = k0 + 1;
+        c1 = at(i - si, j - sj, k - sk); c2 = at(i - si, j, k - sk); c3 = at(i - si, j - sj, k); c4 = at(i - si, j, k);
+    }
+    if (n == 0) {
+        cd = __builtin_nan("");
+        path = __builtin_nan("");
+    } else {
+        cinterp_sector(n, a, b, su, sv, u1, v1, c1, c2, c3, c4, sigma, fortran_constants ? SQRT3_F32 : SQRT3_CUDA,
+                       fortran_constants ? SQRT2_F32 : SQRT2_CUDA, cd, path);
+    }
+    const int idx = threadIdx.z + blockDim.z * (threadIdx.y + blockDim.y * threadIdx.x);
+    out[2 * idx] = cd;
+    out[2 * idx + 1] = path;
+}
+
+}  // namespace asora
