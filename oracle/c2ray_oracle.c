@@ -72,6 +72,46 @@ static double photo_lookuptable(double tau, const double *table, double minlogta
     return table[a] + residual * (table[b] - table[a]);
 }
 
+/* Conditioning probe (NOT part of the reference): the same lookup with the libm log10 result moved by
+ * `shift` ulps.  Used to measure how much a rate depends on the last bit of log10, i.e. how far two
+ * correct implementations with different libm's may legitimately differ in that cell. */
+static double photo_lookuptable_shift(double tau, const double *table, double minlogtau, double dlogtau,
+                                      int NumTau, int shift) {
+    double logtau = log10(fmax(1.0e-20, tau));
+    for (int s = 0; s < (shift < 0 ? -shift : shift); s++) logtau = nextafter(logtau, shift < 0 ? -INFINITY : INFINITY);
+    double real_i = fmin((double)(float)NumTau, fmax(0.0, 1.0 + (logtau - minlogtau) / dlogtau));
+    int i0 = (int)real_i;
+    int i1 = i_min(NumTau, i0 + 1);
+    double residual = real_i - (double)(float)i0;
+    int a = i_min(i0, NumTau - 1), b = i_min(i1, NumTau - 1);
+    return table[a] + residual * (table[b] - table[a]);
+}
+
+static double lookup_spread(double tau, const double *table, double minlogtau, double dlogtau, int NumTau) {
+    double c = photo_lookuptable_shift(tau, table, minlogtau, dlogtau, NumTau, 0);
+    double p = photo_lookuptable_shift(tau, table, minlogtau, dlogtau, NumTau, 1);
+    double m = photo_lookuptable_shift(tau, table, minlogtau, dlogtau, NumTau, -1);
+    return fmax(fabs(p - c), fabs(m - c));
+}
+
+/* |d rate| for a +-1 ulp change of the log10 calls inside photoion_rates (before the division by nHI) */
+void c2ray_photoion_rates_sens(double normflux, double coldens_in, double coldens_out, double Vfact, double sig,
+                               double *sens_photo, double *sens_heat, const double *photo_thin_table,
+                               const double *photo_thick_table, const double *heat_thin_table,
+                               const double *heat_thick_table, double minlogtau, double dlogtau, int NumTau) {
+    const double tau_photo_limit = (double)1.0e-7f;
+    double tau_in = coldens_in * sig, tau_out = coldens_out * sig, prefact = normflux / Vfact;
+    if (fabs(tau_out - tau_in) > tau_photo_limit) {
+        *sens_photo = fabs(prefact) * (lookup_spread(tau_in, photo_thick_table, minlogtau, dlogtau, NumTau) +
+                                       lookup_spread(tau_out, photo_thick_table, minlogtau, dlogtau, NumTau));
+        *sens_heat = fabs(prefact) * (lookup_spread(tau_in, heat_thick_table, minlogtau, dlogtau, NumTau) +
+                                      lookup_spread(tau_out, heat_thick_table, minlogtau, dlogtau, NumTau));
+    } else {
+        *sens_photo = fabs(prefact * (tau_out - tau_in)) * lookup_spread(tau_in, photo_thin_table, minlogtau, dlogtau, NumTau);
+        *sens_heat = fabs(prefact * (tau_out - tau_in)) * lookup_spread(tau_in, heat_thin_table, minlogtau, dlogtau, NumTau);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * photorates.f90:62-149  photoion_rates
  * ---------------------------------------------------------------------------------------- */
@@ -244,7 +284,18 @@ typedef struct {
     int NumTau, m1, m2, m3;
     int flux_mode;
     long long visits; /* statistics: number of cells actually evaluated */
+    double *phi_sens, *heat_sens; /* optional conditioning grids (see c2ray_set_sens_outputs) */
 } rt_ctx;
+
+static double *g_phi_sens = 0, *g_heat_sens = 0;
+/* Register (or clear, with NULLs) N^3 grids that the next c2ray_do_all_sources calls fill with the
+ * summed per-source sensitivity of phi_ion / phi_heat to a +-1 ulp change of log10.  Zeroed here. */
+void c2ray_set_sens_outputs(double *phi_sens, double *heat_sens, long long ncell) {
+    g_phi_sens = phi_sens;
+    g_heat_sens = heat_sens;
+    if (phi_sens) memset(phi_sens, 0, (size_t)ncell * sizeof(double));
+    if (heat_sens) memset(heat_sens, 0, (size_t)ncell * sizeof(double));
+}
 
 /* ------------------------------------------------------------------------------------------
  * raytracing.f90:347-567  evolve0D
@@ -285,6 +336,13 @@ static void evolve0D(rt_ctx *c, const int *rtpos, const int *last_l, const int *
             c2ray_photoion_rates(flux, coldensh_in, cdo, vol_ph, c->sig, &phi_ion_p, &phi_ion_out,
                                  &phi_heat_p, c->thin, c->thick, c->hthin, c->hthick, c->minlogtau,
                                  c->dlogtau, c->NumTau);
+            if (c->phi_sens) {
+                double sp_, sh_;
+                c2ray_photoion_rates_sens(flux, coldensh_in, cdo, vol_ph, c->sig, &sp_, &sh_, c->thin, c->thick,
+                                          c->hthin, c->hthick, c->minlogtau, c->dlogtau, c->NumTau);
+                c->phi_sens[id] += fabs(sp_ / nHI_p);
+                if (c->heat_sens) c->heat_sens[id] += fabs(sh_ / nHI_p);
+            }
         } else {
             phi_ion_p = 0.0;
         }
@@ -374,6 +432,7 @@ long long c2ray_do_all_sources(const double *normflux, const int *srcpos, int ma
     c.thin = photo_thin_table; c.thick = photo_thick_table; c.hthin = heat_thin_table; c.hthick = heat_thick_table;
     c.minlogtau = minlogtau; c.dlogtau = dlogtau; c.R_max_LLS = R_max_LLS; c.NumTau = NumTau;
     c.m1 = m1; c.m2 = m2; c.m3 = m3; c.flux_mode = flux_mode; c.visits = 0;
+    c.phi_sens = g_phi_sens; c.heat_sens = g_heat_sens;
     *sum_nbox = 0;
     *photon_loss = 0.0;
     for (int ns = 0; ns < NumSrc; ns++) {

@@ -69,6 +69,8 @@ class PortOracle:
         L.c2ray_photoion_rates.restype = None
         L.c2ray_photoion_rates.argtypes = [C.c_double] * 5 + [_dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double,
                                                                C.c_double, C.c_int]
+        L.c2ray_set_sens_outputs.restype = None
+        L.c2ray_set_sens_outputs.argtypes = [_dp, _dp, C.c_longlong]
         L.c2ray_asora_visit_count.restype = None
         L.c2ray_asora_visit_count.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_longlong),
                                               C.POINTER(C.c_longlong)]
@@ -76,8 +78,10 @@ class PortOracle:
     # -- raytracing -------------------------------------------------------------------
     def do_all_sources(self, flux, pos0, ndens, xh_av, sig, dr, thin, thick, minlogtau, dlogtau, R,
                        heat_thin=None, heat_thick=None, max_subbox=None, subboxsize=None, loss_fraction=0.0,
-                       flux_mode=1, num_tau=None):
-        """pos0: (Ns,3) 0-based.  Returns dict(phi_ion, phi_heat, coldensh_out, nsubbox, photon_loss, visits)."""
+                       flux_mode=1, num_tau=None, sens=False):
+        """pos0: (Ns,3) 0-based.  sens=True also returns phi_sens / heat_sens: per cell, the summed change of
+        each source's rate under a +-1 ulp change of the libm log10 results (conditioning of the
+        reference value itself; see tests/parity.py).  Returns dict(phi_ion, phi_heat, coldensh_out, nsubbox, photon_loss, visits)."""
         N = ndens.shape[0]
         flux = np.ascontiguousarray(flux, dtype=np.float64)
         pos1 = np.ascontiguousarray(np.asarray(pos0, dtype=np.int32).reshape(-1, 3) + 1)  # [ns][d] == (3,Ns) F-order
@@ -98,13 +102,20 @@ class PortOracle:
         heat = np.zeros((N, N, N))
         nbox = C.c_int(0)
         loss = C.c_double(0.0)
+        psens = hsens = None
+        if sens:
+            psens, hsens = np.zeros((N, N, N)), np.zeros((N, N, N))
+            self.lib.c2ray_set_sens_outputs(_d(psens), _d(hsens), N ** 3)
+        else:
+            self.lib.c2ray_set_sens_outputs(None, None, 0)
         visits = self.lib.c2ray_do_all_sources(
             _d(flux), pos1.ctypes.data_as(_ip), int(max_subbox), int(subboxsize), _d(cdh), float(sig), float(dr),
             _d(nd), _d(xh), _d(phi), _d(heat), C.byref(nbox), C.byref(loss), float(loss_fraction), _d(thin),
             _d(thick), _d(ht), _d(hk), float(minlogtau), float(dlogtau), float(R), NumTau, Ns, N, N, N,
             int(flux_mode))
+        self.lib.c2ray_set_sens_outputs(None, None, 0)
         return dict(phi_ion=phi, phi_heat=heat, coldensh_out=cdh, nsubbox=nbox.value, photon_loss=loss.value,
-                    visits=int(visits))
+                    visits=int(visits), phi_sens=psens, heat_sens=hsens)
 
     def cinterp(self, pos0, srcpos0, cdh, sigma):
         """0-based positions (pos may lie outside the box: it is wrapped like the reference does)."""

@@ -164,9 +164,9 @@ def reference_test_case(N=50, ns=10, R=15.0, numtau=20000):
                 pos=src_pos.reshape(ns, 3), flux=flux, pos_flat=src_pos)
 
 
-def run_oracle(oracle, c, heat=True, flux_mode=1):
+def run_oracle(oracle, c, heat=True, flux_mode=1, **kw):
     return oracle.do_all_sources(c["flux"], c["pos"], c["ndens"], c["xh"], c["sig"], c["dr"], c["thin"],
                                  c["thick"], c["minlogtau"], c["dlogtau"], c["R"],
                                  heat_thin=c["heat_thin"] if heat else None,
                                  heat_thick=c["heat_thick"] if heat else None, num_tau=c["num_tau"],
-                                 flux_mode=flux_mode)
+                                 flux_mode=flux_mode, **kw)

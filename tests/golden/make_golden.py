@@ -45,7 +45,7 @@ def main():
     for name, fn in cases.CASES.items():
         c = fn()
         r = cases.run_oracle(ref, c)
-        p = cases.run_oracle(port, c)
+        p = cases.run_oracle(port, c, sens=True)
         assert np.array_equal(r["coldensh_out"], p["coldensh_out"]), name
         e = relerr(p["phi_ion"], r["phi_ion"])
         assert e <= 1e-13, (name, e)
@@ -62,7 +62,10 @@ def main():
             heat_thick=c["heat_thick"], ndens=c["ndens"], xh=c["xh"], pos=c["pos"], flux=c["flux"],
             phi_ion=r["phi_ion"], phi_heat=r["phi_heat"], heat_valid=name in HEAT_VALID,
             coldensh_last=r["coldensh_out"], phi_ion_lastflux_bug=r0["phi_ion"],
-            photon_loss=r["photon_loss"], nsubbox=r["nsubbox"])
+            photon_loss=r["photon_loss"], nsubbox=r["nsubbox"],
+            # conditioning of the reference values (from the port, see oracle/c2ray_oracle.c
+            # c2ray_photoion_rates_sens); float32 is plenty for a tolerance term
+            phi_sens=p["phi_sens"].astype(np.float32), heat_sens=p["heat_sens"].astype(np.float32))
         print(f"{name:22s} N={c['N']:3d} Ns={len(c['flux']):2d} port-vs-ref phi rel {e:.1e}  max phi {r['phi_ion'].max():.3e}")
 
     # cinterp known-answer vectors: inputs of the reference test, outputs of the Fortran cinterp
