@@ -1,0 +1,102 @@
+"""CPU tests: the oracle against the committed golden vectors (which come from the reference
+Fortran, tests/golden/make_golden.py) and, when oracle/_ref was built, against the reference itself."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle.oracle import REF_SO, PortOracle, RefOracle
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def relmax(a, b):
+    m = b != 0
+    return float(np.max(np.abs(a[m] - b[m]) / np.abs(b[m]))) if m.any() else 0.0
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_port_vs_golden(port_oracle, golden_dir, name):
+    g = load(golden_dir, name)
+    c = cases.CASES[name]()
+    # the generator must reproduce the stored inputs exactly (same seeds, same numpy)
+    for k in ("ndens", "xh", "pos", "flux"):
+        assert np.array_equal(c[k], g[k]), k
+    np.testing.assert_allclose(c["thick"], g["thick"], rtol=1e-12)
+    c.update(thin=g["thin"], thick=g["thick"], heat_thin=g["heat_thin"], heat_thick=g["heat_thick"])
+    o = cases.run_oracle(port_oracle, c)
+    assert np.array_equal(o["coldensh_out"], g["coldensh_last"])          # no libm log10 involved: bit-exact
+    assert np.array_equal(o["phi_ion"] != 0, g["phi_ion"] != 0)
+    assert relmax(o["phi_ion"], g["phi_ion"]) <= 1e-12                    # libm log10 variants only
+    if bool(g["heat_valid"]):
+        assert relmax(o["phi_heat"], g["phi_heat"]) <= 1e-12
+    o0 = cases.run_oracle(port_oracle, c, flux_mode=0)                    # reference bug mode (last flux for all)
+    assert relmax(o0["phi_ion"], g["phi_ion_lastflux_bug"]) <= 1e-12
+
+
+def test_cinterp_kat(port_oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "cinterp_kat.npz"))
+    dens = np.random.default_rng(seed=42).random((20, 20, 20), dtype=np.float64)
+    for pos0 in [(5, 5, 5), (1, 2, 3), (10, 5, 15)]:
+        exp = z["%02d%02d%02d" % pos0]
+        for i in range(4):
+            for j in range(4):
+                for k in range(4):
+                    if i == j == k == 0:
+                        continue
+                    got = port_oracle.cinterp((pos0[0] + i, pos0[1] + j, pos0[2] + k), pos0, dens, 1.0)
+                    assert tuple(exp[i, j, k]) == got
+
+
+def test_cinterp_float32_sqrt_signature(port_oracle):
+    """the body-diagonal neighbour carries sqrt(3.0) in single precision."""
+    cd = np.ones((8, 8, 8))
+    v, path = port_oracle.cinterp((4, 4, 4), (3, 3, 3), cd, 1e-30)
+    assert v == float(np.float32(3.0) ** np.float32(0.5)) and v != np.sqrt(3.0)
+    assert path == np.sqrt(3.0)
+
+
+def test_last_flux_bug_is_reproduced(port_oracle):
+    """with flux_mode=0 two sources (flux 1, 3) == both sources with flux 3."""
+    c = cases.case_rcut7p3()
+    a = cases.run_oracle(port_oracle, dict(c, flux=np.array([1.0, 3.0])), flux_mode=0)["phi_ion"]
+    b = cases.run_oracle(port_oracle, dict(c, flux=np.array([3.0, 3.0])), flux_mode=1)["phi_ion"]
+    assert np.array_equal(a, b)
+
+
+def test_subbox_early_exit_and_photon_loss(port_oracle):
+    """USE_SUBBOX semantics (raytracing.f90:193-221): a generous loss_fraction stops after one subbox."""
+    c = cases.case_uniform32_center()
+    kw = dict(heat_thin=None, heat_thick=None, num_tau=c["num_tau"])
+    full = port_oracle.do_all_sources(c["flux"], c["pos"], c["ndens"], c["xh"], c["sig"], c["dr"], c["thin"], c["thick"],
+                                      c["minlogtau"], c["dlogtau"], c["R"], max_subbox=1000, subboxsize=4,
+                                      loss_fraction=0.0, **kw)
+    early = port_oracle.do_all_sources(c["flux"], c["pos"], c["ndens"], c["xh"], c["sig"], c["dr"], c["thin"], c["thick"],
+                                       c["minlogtau"], c["dlogtau"], c["R"], max_subbox=1000, subboxsize=4,
+                                       loss_fraction=0.999999, **kw)
+    assert full["nsubbox"] == 4 and early["nsubbox"] == 1
+    assert full["visits"] == 32 ** 3 and early["visits"] == 9 ** 3
+    assert early["photon_loss"] > full["photon_loss"] >= 0
+    sl = (slice(12, 21),) * 3
+    assert np.array_equal(full["phi_ion"][sl], early["phi_ion"][sl])   # growing boxes re-use finished cells
+
+
+def test_visit_count(port_oracle):
+    assert port_oracle.asora_visit_count(60, 256) == (1521729, 904089)
+    assert port_oracle.asora_visit_count(1e3, 128)[0] == 128 ** 3
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (needs /root/reference + amdflang)")
+def test_port_vs_compiled_reference(port_oracle):
+    ref = RefOracle()
+    c = cases.case_multi16_unequal()
+    c = dict(c, pos=c["pos"][:4], flux=c["flux"][:4])
+    a, b = cases.run_oracle(ref, c), cases.run_oracle(port_oracle, c)
+    assert np.array_equal(a["coldensh_out"], b["coldensh_out"])
+    assert relmax(b["phi_ion"], a["phi_ion"]) <= 1e-13
+    a0, b0 = cases.run_oracle(ref, c, flux_mode=0), cases.run_oracle(port_oracle, c, flux_mode=0)
+    assert relmax(b0["phi_ion"], a0["phi_ion"]) <= 1e-13
