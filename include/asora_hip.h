@@ -102,6 +102,18 @@ int asora_last_sweep_ms(float *ms);
 /* Name of the sweep kernel and its launch geometry of the last call (for profile matching). */
 int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_is_lds);
 
+/* Tuning / test switches: "force_generic" (1: always run the table-free sweep kernel),
+ * "max_table_cells" (geometry-table budget in cells; larger problems use the table-free kernel). */
+int asora_set_option(const char *name, long long value);
+
+/* 1 if the last sweep ran the table-driven kernel, 0 for the table-free one. */
+int asora_last_sweep_is_table_driven(void);
+
+/* Device self-test: counts the inputs for which the kernels' division helpers (div_exact,
+ * rcp_exact, div_const) differ in any bit from the compiler's IEEE-754 division num[i]/den[i]. */
+int asora_test_division(const double *num, const double *den, long long n, long long *mismatch_div,
+                        long long *mismatch_rcp, long long *mismatch_const);
+
 const char *asora_last_error(void);
 
 #ifdef __cplusplus

@@ -7,6 +7,7 @@
 #include "asora_kernels.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -58,6 +59,16 @@ struct State {
     int *src_pos = nullptr;
     double *src_flux = nullptr;
     int num_src = 0;
+    // geometry tables of the table-driven sweep (cached per (N, R, dr))
+    asora::PlaneInfo *planes_dev = nullptr;
+    uint32_t *cell_ab_dev = nullptr;
+    double *cell_pathdr_dev = nullptr, *cell_vol_dev = nullptr;
+    int geo_N = 0, geo_nplanes = 0, geo_vmap[8] = {0};
+    double geo_R = -1.0, geo_dr = -1.0;
+    bool geo_valid = false;
+    int force_generic = 0;        // option "force_generic": always use the table-free kernel
+    long long max_table_cells = 48LL << 20;  // option "max_table_cells": beyond this the generic kernel runs
+    int last_tab = 0;
     // staging scratch for planes that do not fit in LDS
     double *gscratch = nullptr;
     size_t gscratch_bytes = 0;
@@ -98,6 +109,109 @@ int upload_table(double *&dev, const double *host, int n) {
 int compute_q_max(double R, int m1) {
     const double SQRT3 = 1.73205080757;
     return (int)std::ceil(SQRT3 * std::min(R, SQRT3 * m1 / 2.0));
+}
+
+// ------------------------------------------------------------------------------------------
+// Geometry tables for sweep_tab_kernel.  For each distinct (limit_u, limit_v, summation order)
+// variant and each plane n: list A = cells with dist2/dr2 <= R2 evaluated EXACTLY as the oracle does
+// (raytracing.f90:448-451,474: xs = dr*real(di), dist2 = xs*xs + ys*ys + zs*zs in x,y,z order,
+// no contraction -- this file is compiled with -ffp-contract=off for the host too), list B = the
+// other cells of octahedron ∩ box.  path = sqrt((a^2+b^2)/n^2 + 1) (raytracing.f90:710), stored
+// as path*dr, and vol_ph = dist2*path*dr*4pi (raytracing.f90:457).
+// ------------------------------------------------------------------------------------------
+void free_geometry() {
+    if (S.planes_dev) (void)hipFree(S.planes_dev);
+    if (S.cell_ab_dev) (void)hipFree(S.cell_ab_dev);
+    if (S.cell_pathdr_dev) (void)hipFree(S.cell_pathdr_dev);
+    if (S.cell_vol_dev) (void)hipFree(S.cell_vol_dev);
+    S.planes_dev = nullptr; S.cell_ab_dev = nullptr; S.cell_pathdr_dev = nullptr; S.cell_vol_dev = nullptr;
+    S.geo_valid = false;
+}
+
+long long geometry_cells_per_variant(int q_max, int lim, int nmaxmax) {
+    long long c = 0;
+    for (int n = 1; n <= nmaxmax; n++) {
+        const int cut = q_max - n, h = std::min(std::min(n, lim), cut) + 1;
+        c += (long long)h * h;
+    }
+    return c;
+}
+
+int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r, hipStream_t st) {
+    if (S.geo_valid && S.geo_N == N && S.geo_R == R && S.geo_dr == dr) return 0;
+    if (S.geo_valid) HIP_TRY(hipStreamSynchronize(st));  // tables may still be in use by a previous launch
+    free_geometry();
+    const int nmaxmax = std::min(std::max(last_l, last_r), q_max);
+    const int nplanes = nmaxmax + 1;
+    int cap = 0;  // widest in-plane extent the octahedron allows
+    for (int n = 1; n <= nmaxmax; n++) cap = std::max(cap, std::min(n, q_max - n));
+    const double R2 = R * R, dr2 = dr * dr;
+    std::vector<asora::PlaneInfo> planes;
+    std::vector<uint32_t> ab;
+    std::vector<double> pathdr, vol;
+    std::vector<std::array<int, 3>> keys;  // (LU, LV, order)
+    for (int code = 0; code < 8; code++) {
+        const int LU = std::min((code & 4) ? last_l : last_r, cap), LV = std::min((code & 2) ? last_l : last_r, cap);
+        const int order = code & 1;  // 0: z-sector (U2+V2)+P2, 1: x/y-sector (U2+P2)+V2
+        int found = -1;
+        for (size_t k = 0; k < keys.size(); k++)
+            if (keys[k][0] == LU && keys[k][1] == LV && keys[k][2] == order) found = (int)k;
+        if (found >= 0) { S.geo_vmap[code] = found; continue; }
+        S.geo_vmap[code] = (int)keys.size();
+        keys.push_back({LU, LV, order});
+        planes.resize(planes.size() + nplanes);
+        asora::PlaneInfo *pl = planes.data() + planes.size() - nplanes;
+        pl[0] = {0, 0, 0, 0};
+        for (int n = 1; n <= nmaxmax; n++) {
+            const int cut = q_max - n;
+            const int H = std::min(std::min(n, LU), cut) + 1, W = std::min(std::min(n, LV), cut) + 1;
+            const double dn = (double)n;
+            const double P2 = (dr * dn) * (dr * dn);
+            pl[n].off = (uint32_t)ab.size();
+            pl[n].pad = 0;
+            for (int pass = 0; pass < 2; pass++) {
+                for (int a = 0; a < H; a++) {
+                    const int bend = std::min(W - 1, cut - a);
+                    const double U2 = (dr * (double)a) * (dr * (double)a);
+                    for (int b = 0; b <= bend; b++) {
+                        const double V2 = (dr * (double)b) * (dr * (double)b);
+                        const double dist2 = order == 0 ? (U2 + V2) + P2 : (U2 + P2) + V2;
+                        const bool stop = dist2 / dr2 > R2;
+                        if (stop != (pass == 1)) continue;
+                        const double path = std::sqrt((double)(a * a + b * b) / (dn * dn) + 1.0);
+                        const double pd = path * dr;
+                        ab.push_back(((uint32_t)a << 16) | (uint32_t)b);
+                        pathdr.push_back(pd);
+                        vol.push_back(dist2 * pd * asora::FOURPI);
+                    }
+                }
+                if (pass == 0) pl[n].cntA = (uint32_t)ab.size() - pl[n].off;
+            }
+            pl[n].cntT = (uint32_t)ab.size() - pl[n].off;
+        }
+    }
+    if (ab.empty()) { ab.push_back(0); pathdr.push_back(0); vol.push_back(0); }
+    HIP_TRY(hipMalloc(&S.planes_dev, planes.size() * sizeof(asora::PlaneInfo)));
+    HIP_TRY(hipMalloc(&S.cell_ab_dev, ab.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&S.cell_pathdr_dev, pathdr.size() * sizeof(double)));
+    HIP_TRY(hipMalloc(&S.cell_vol_dev, vol.size() * sizeof(double)));
+    // synchronous copies: the host vectors die at the end of this function
+    HIP_TRY(hipMemcpy(S.planes_dev, planes.data(), planes.size() * sizeof(asora::PlaneInfo), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(S.cell_ab_dev, ab.data(), ab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(S.cell_pathdr_dev, pathdr.data(), pathdr.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(S.cell_vol_dev, vol.data(), vol.size() * sizeof(double), hipMemcpyHostToDevice));
+    S.geo_N = N; S.geo_R = R; S.geo_dr = dr; S.geo_nplanes = nplanes; S.geo_valid = true;
+    return 0;
+}
+
+template <bool L, bool H>
+int launch_sweep_tab(const asora::SweepArgs &A, int grid, size_t lds, hipStream_t st) {
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)asora::sweep_tab_kernel<L, H>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((asora::sweep_tab_kernel<L, H>), dim3(grid), dim3(asora::SWEEP_THREADS), lds, st, A);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 template <bool L, bool H>
@@ -169,6 +283,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     A.last_l = N / 2;
     A.num_tau = num_tau;
     A.R = R; A.sig = sig; A.dr = dr; A.minlogtau = minlogtau; A.dlogtau = dlogtau;
+    A.rdlogtau = 1.0 / dlogtau;
     // widest plane any sector stages: max_n min(n, lim, q_max - n) + 1, lim = max(last_l, last_r)
     int wmax = 0;
     {
@@ -197,9 +312,25 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             }
             A.gscratch = S.gscratch;
         }
+        const int nmaxmax = std::min(std::max(A.last_l, A.last_r), A.q_max);
+        const bool use_tab = !S.force_generic && N < 65536 &&
+                             8 * geometry_cells_per_variant(A.q_max, std::max(A.last_l, A.last_r), nmaxmax) <=
+                                 S.max_table_cells;
+        if (use_tab) {
+            if (int rc2 = build_geometry(N, R, dr, A.q_max, A.last_l, A.last_r, st)) return rc2;
+            A.planes = S.planes_dev; A.cell_ab = S.cell_ab_dev; A.cell_pathdr = S.cell_pathdr_dev;
+            A.cell_vol = S.cell_vol_dev; A.nplanes = S.geo_nplanes;
+            for (int i = 0; i < 8; i++) A.vmap[i] = S.geo_vmap[i];
+        }
+        S.last_tab = use_tab ? 1 : 0;
         HIP_TRY(hipEventRecord(S.ev0, st));
-        if (use_lds) rc = want_heat ? launch_sweep<true, true>(A, grid, lds, st) : launch_sweep<true, false>(A, grid, lds, st);
-        else rc = want_heat ? launch_sweep<false, true>(A, grid, 0, st) : launch_sweep<false, false>(A, grid, 0, st);
+        if (use_tab) {
+            if (use_lds) rc = want_heat ? launch_sweep_tab<true, true>(A, grid, lds, st) : launch_sweep_tab<true, false>(A, grid, lds, st);
+            else rc = want_heat ? launch_sweep_tab<false, true>(A, grid, 0, st) : launch_sweep_tab<false, false>(A, grid, 0, st);
+        } else {
+            if (use_lds) rc = want_heat ? launch_sweep<true, true>(A, grid, lds, st) : launch_sweep<true, false>(A, grid, lds, st);
+            else rc = want_heat ? launch_sweep<false, true>(A, grid, 0, st) : launch_sweep<false, false>(A, grid, 0, st);
+        }
         if (rc) return rc;
         HIP_TRY(hipEventRecord(S.ev1, st));
         S.timed = true;
@@ -295,9 +426,14 @@ int asora_device_close(void) {
     for (double **g : grids) free_ptr(*g);
     if (S.src_pos) (void)hipFree(S.src_pos);
     S.src_pos = nullptr;
+    free_geometry();
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
-    S = State();
+    State fresh;  // options and the last launch record survive a close
+    fresh.force_generic = S.force_generic; fresh.max_table_cells = S.max_table_cells;
+    fresh.last_tab = S.last_tab; fresh.last_grid = S.last_grid; fresh.last_block = S.last_block;
+    fresh.last_lds = S.last_lds; fresh.last_is_lds = S.last_is_lds;
+    S = fresh;
     return 0;
 }
 
@@ -449,6 +585,38 @@ int asora_last_sweep_ms(float *ms) {
     if (!S.init || !S.timed) return fail(11, "asora_last_sweep_ms: no sweep has been timed");
     HIP_TRY(hipEventSynchronize(S.ev1));
     HIP_TRY(hipEventElapsedTime(ms, S.ev0, S.ev1));
+    return 0;
+}
+
+int asora_set_option(const char *name, long long value) {
+    if (!name) return fail(9, "asora_set_option: null name");
+    if (!std::strcmp(name, "force_generic")) S.force_generic = value != 0;
+    else if (!std::strcmp(name, "max_table_cells")) S.max_table_cells = value;
+    else return fail(12, "asora_set_option: unknown option '%s'", name);
+    return 0;
+}
+
+int asora_last_sweep_is_table_driven(void) { return S.last_tab; }
+
+int asora_test_division(const double *num, const double *den, long long n, long long *mismatch_div,
+                        long long *mismatch_rcp, long long *mismatch_const) {
+    if (!num || !den || n < 1 || !mismatch_div || !mismatch_rcp || !mismatch_const)
+        return fail(9, "asora_test_division: bad arguments");
+    double *d_n = nullptr, *d_d = nullptr;
+    unsigned long long *d_c = nullptr;
+    HIP_TRY(hipMalloc(&d_n, n * sizeof(double)));
+    HIP_TRY(hipMalloc(&d_d, n * sizeof(double)));
+    HIP_TRY(hipMalloc(&d_c, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpy(d_n, num, n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d, den, n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_c, 0, 3 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(asora::division_test_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d_n, d_d,
+                       n, d_c);
+    HIP_TRY(hipGetLastError());
+    unsigned long long c[3];
+    HIP_TRY(hipMemcpy(c, d_c, sizeof c, hipMemcpyDeviceToHost));
+    (void)hipFree(d_n); (void)hipFree(d_d); (void)hipFree(d_c);
+    *mismatch_div = (long long)c[0]; *mismatch_rcp = (long long)c[1]; *mismatch_const = (long long)c[2];
     return 0;
 }
 

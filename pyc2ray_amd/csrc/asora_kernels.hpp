@@ -36,6 +36,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace asora {
 
 constexpr int SWEEP_THREADS = 256;
@@ -45,6 +47,12 @@ constexpr double SQRT3_F32 = 1.7320507764816284;                // (double)sqrtf
 constexpr double SQRT2_F32 = 1.4142135381698608;                // (double)sqrtf(2.0f), raytracing.f90:609
 constexpr double SQRT3_CUDA = 1.73205080757;                    // src/asora/raytracing.cu:20-21
 constexpr double SQRT2_CUDA = 1.41421356237;
+
+// One plane of one geometry variant in the cell tables: cells [off, off+cntA) produce rates
+// (dist2/dr2 <= R2 with the oracle's exact arithmetic), [off+cntA, off+cntT) only propagate cdh.
+struct PlaneInfo {
+    uint32_t off, cntA, cntT, pad;
+};
 
 struct SweepArgs {
     const double *nhiA;  // nHI, [i][j][k]
@@ -64,7 +72,46 @@ struct SweepArgs {
     int plane_elems;        // rows * S
     int num_tau;
     double R, sig, dr, minlogtau, dlogtau;
+    double rdlogtau;        // correctly rounded 1/dlogtau (host)
+    // table-driven fast path (sweep_tab_kernel)
+    const PlaneInfo *planes;   // [variant][nplanes]
+    const uint32_t *cell_ab;   // (a << 16) | b, list A (rate-producing) then list B per plane
+    const double *cell_pathdr; // path * dr
+    const double *cell_vol;    // vol_ph = dist2 * (path*dr) * 4pi
+    int nplanes;
+    int vmap[8];               // ((u_is_neg*2 + v_is_neg)*2 + (axis != 0)) -> variant
 };
+
+// ------------------------------------------------------------------------------------------
+// IEEE-exact f64 division without the range-handling instructions.  hipcc expands a/b into
+// v_div_scale x2, v_rcp, two Newton steps on the reciprocal, q = a*r, one residual correction
+// (v_div_fmas) and v_div_fixup.  The scale/fixup instructions only matter when an operand or the
+// quotient is subnormal / near overflow; every divisor on this path is a normal number far from
+// both ends (0.6 <= max(0.6, tau), sums of positive weights, cell volumes, densities, table
+// steps), so the same Newton + correction sequence without them gives the identical, correctly
+// rounded quotient in 8 instead of 12 instructions (checked bit-for-bit on the GPU against `/`
+// by asora_test_division, tests/test_gpu_parity.py::test_exact_division_helpers).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_refined(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double div_exact(double n, double d) {
+    const double r = rcp_refined(d);
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+__device__ __forceinline__ double rcp_exact(double d) {  // 1.0 / d
+    const double r = rcp_refined(d);
+    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+}
+// x / d with rd = the correctly rounded 1/d computed once (Markstein's correction step)
+__device__ __forceinline__ double div_const(double x, double d, double rd) {
+    const double q = x * rd;
+    return __builtin_fma(__builtin_fma(-d, q, x), rd, q);
+}
 
 struct Lookup {
     int i0;
@@ -72,9 +119,10 @@ struct Lookup {
 };
 
 // photorates.f90:139-143 (index part of photo_lookuptable); log10 is the device library's.
-__device__ __forceinline__ Lookup table_index(double tau, double minlogtau, double dlogtau, int num_tau) {
+__device__ __forceinline__ Lookup table_index(double tau, double minlogtau, double dlogtau, double rdlogtau,
+                                              int num_tau) {
     double logtau = log10(fmax(1.0e-20, tau));
-    double real_i = fmin((double)num_tau, fmax(0.0, 1.0 + (logtau - minlogtau) / dlogtau));
+    double real_i = fmin((double)num_tau, fmax(0.0, 1.0 + div_const(logtau - minlogtau, dlogtau, rdlogtau)));
     Lookup L;
     L.i0 = (int)real_i;
     L.residual = real_i - (double)L.i0;
@@ -94,11 +142,11 @@ __device__ __forceinline__ void cell_rates(const SweepArgs &A, double flux, doub
     const double tau_photo_limit = (double)1.0e-7f;
     double tau_in = cdh_in * A.sig;
     double tau_out = cdh_out * A.sig;
-    double prefact = flux / vol_ph;
-    Lookup Lin = table_index(tau_in, A.minlogtau, A.dlogtau, A.num_tau);
+    double prefact = div_exact(flux, vol_ph);
+    Lookup Lin = table_index(tau_in, A.minlogtau, A.dlogtau, A.rdlogtau, A.num_tau);
     double phi_in = prefact * table_eval(A.thick, Lin);
     if (fabs(tau_out - tau_in) > tau_photo_limit) {
-        Lookup Lout = table_index(tau_out, A.minlogtau, A.dlogtau, A.num_tau);
+        Lookup Lout = table_index(tau_out, A.minlogtau, A.dlogtau, A.rdlogtau, A.num_tau);
         double phi_out = prefact * table_eval(A.thick, Lout);
         phi = phi_in - phi_out;
         if (HEAT) heat = prefact * (table_eval(A.hthick, Lin) - table_eval(A.hthick, Lout));
@@ -106,23 +154,22 @@ __device__ __forceinline__ void cell_rates(const SweepArgs &A, double flux, doub
         phi = prefact * (tau_out - tau_in) * table_eval(A.thin, Lin);
         if (HEAT) heat = prefact * (tau_out - tau_in) * table_eval(A.hthin, Lin);
     }
-    phi = phi / nHI;
-    if (HEAT) heat = heat / nHI;
+    phi = div_exact(phi, nHI);
+    if (HEAT) heat = div_exact(heat, nHI);
 }
 
 // raytracing.f90:807-813
-__device__ __forceinline__ double weightf(double cd, double sig) { return 1.0 / fmax(0.6, cd * sig); }
+__device__ __forceinline__ double weightf(double cd, double sig) { return rcp_exact(fmax(0.6, cd * sig)); }
 
 // The interpolation of raytracing.f90:662-710 / 715-758 / 764-800 in sector coordinates.
 //   n >= 1 : distance along the dominant axis;  a, b >= 0 : in-plane distances (u, v axes)
 //   su, sv : signs of the in-plane offsets;  u1, v1 : 1-BASED source coordinates on those axes
 //            (the oracle's crossing point xc = alam*di + real(i0) carries the absolute position)
+//   alam   : ((n-1) + 0.5)/n, the oracle's (real(km-k0)+sgnk*0.5)/dk  (sign-free)
 //   c1..c4 : outgoing column densities of (a-1,b-1), (a,b-1), (a-1,b), (a,b) in plane n-1
-__device__ __forceinline__ void cinterp_sector(int n, int a, int b, int su, int sv, int u1, int v1, double c1,
-                                               double c2, double c3, double c4, double sig, double sqrt3,
-                                               double sqrt2, double &cdensi, double &path) {
-    double dn = (double)n;
-    double alam = (dn - 0.5) / dn;
+__device__ __forceinline__ double cinterp_cd(int n, int a, int b, int su, int sv, int u1, int v1, double alam,
+                                             double c1, double c2, double c3, double c4, double sig,
+                                             double sqrt3, double sqrt2) {
     double dU = (double)(su * a), dV = (double)(sv * b);
     double uc = alam * dU + (double)u1;
     double vc = alam * dV + (double)v1;
@@ -138,12 +185,27 @@ __device__ __forceinline__ void cinterp_sector(int n, int a, int b, int su, int 
     double w2 = s2 * weightf(c2, sig);
     double w3 = s3 * weightf(c3, sig);
     double w4 = s4 * weightf(c4, sig);
-    cdensi = (c1 * w1 + c2 * w2 + c3 * w3 + c4 * w4) / (w1 + w2 + w3 + w4);
+    double cdensi = div_exact(c1 * w1 + c2 * w2 + c3 * w3 + c4 * w4, w1 + w2 + w3 + w4);
     if (n == 1 && (a == 1 || b == 1)) {
         if (a == 1 && b == 1) cdensi = sqrt3 * cdensi;
         else cdensi = sqrt2 * cdensi;
     }
-    path = sqrt((double)(a * a + b * b) / (dn * dn) + 1.0);
+    return cdensi;
+}
+__device__ __forceinline__ double cinterp_alam(int n) {
+    const double dn = (double)n;
+    return div_exact(dn - 0.5, dn);
+}
+// path length through the cell in cell units, raytracing.f90:710 / 758 / 800
+__device__ __forceinline__ double cinterp_path(int n, int a, int b) {
+    const double dn = (double)n;
+    return sqrt(div_exact((double)(a * a + b * b), dn * dn) + 1.0);
+}
+__device__ __forceinline__ void cinterp_sector(int n, int a, int b, int su, int sv, int u1, int v1, double c1,
+                                               double c2, double c3, double c4, double sig, double sqrt3,
+                                               double sqrt2, double &cdensi, double &path) {
+    cdensi = cinterp_cd(n, a, b, su, sv, u1, v1, cinterp_alam(n), c1, c2, c3, c4, sig, sqrt3, sqrt2);
+    path = cinterp_path(n, a, b);
 }
 
 __device__ __forceinline__ int wrap(int x, int N) {
@@ -263,7 +325,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
                 const double V2 = (A.dr * (double)b) * (A.dr * (double)b);
                 const double dist2 = (axis == 0) ? (U2 + V2) + P2 : (U2 + P2) + V2;
                 const double vol_ph = dist2 * path * FOURPI;
-                const bool stop = (dist2 / dr2 > R2) || (cdh_in > max_coldensh);
+                const bool stop = (div_exact(dist2, dr2) > R2) || (cdh_in > max_coldensh);
                 const double cdo = cdh_in + nHI * path;
                 stg.st(cur + (a + 1) * S + b + 1, cdo);
                 // ownership: reference tie order (z, y, x) and sign(0) = +1
@@ -279,6 +341,116 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
                     }
                 }
             }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Table-driven sweep (the fast path).  Same task decomposition and arithmetic as sweep_kernel;
+// everything about a cell that depends only on its offset (n, a, b) from the source -- membership
+// in the octahedron/box, the oracle's exact R-sphere predicate, path*dr and vol_ph -- is computed
+// once per call on the host with the same IEEE operations (build_geometry in asora_capi.hip) and
+// streamed from L2.  Per plane the cells come as two dense lists: A (inside the R sphere: column
+// density + rates) and B (outside: column density only), so wavefronts are fully populated and
+// never diverge on the sphere or the octahedron cut.
+// ------------------------------------------------------------------------------------------
+template <bool LDS_STAGE, bool HEAT>
+__global__ __launch_bounds__(SWEEP_THREADS) void sweep_tab_kernel(SweepArgs A) {
+    Stage<LDS_STAGE> stg;
+    stg.g = LDS_STAGE ? nullptr : A.gscratch + (size_t)blockIdx.x * 2 * (size_t)A.plane_elems;
+    const int tid = threadIdx.x;
+    const int S = A.S;
+    const int plane = A.plane_elems;
+    const int N = A.N;
+    const size_t N2 = (size_t)N * N;
+    const double max_coldensh = (double)2e30f;  // raytracing.f90:368
+
+    for (long long task = blockIdx.x; task < A.ntasks; task += gridDim.x) {
+        const int s = (int)(task / SECTORS);
+        const int t = (int)(task - (long long)s * SECTORS);
+        const int src = A.src_begin + s;
+        const int axis = t >> 3;
+        const int sp = (t & 4) ? -1 : 1;
+        const int su = (t & 2) ? -1 : 1;
+        const int sv = (t & 1) ? -1 : 1;
+        const int i0 = A.src_pos[3 * src + 0], j0 = A.src_pos[3 * src + 1], k0 = A.src_pos[3 * src + 2];
+        const double flux = A.src_flux[src];
+        int p0, u0, v0;
+        if (axis == 0) { p0 = k0; u0 = i0; v0 = j0; }
+        else if (axis == 1) { p0 = j0; u0 = i0; v0 = k0; }
+        else { p0 = i0; u0 = j0; v0 = k0; }
+        const double *__restrict__ nhi = (axis == 0) ? A.nhiB : A.nhiA;
+        double *__restrict__ phi = (axis == 0) ? A.phiB : A.phiA;
+        double *__restrict__ heat = (axis == 0) ? A.heatB : A.heatA;
+        double *__restrict__ cdh = (axis == 0) ? A.cdhB : A.cdhA;
+        const bool write_cdh = (src == A.cdh_src) && (cdh != nullptr);
+        const int nmax = min(sp > 0 ? A.last_r : A.last_l, A.q_max);
+        const size_t strideP = (axis == 2) ? N2 : (size_t)N;
+        const size_t strideU = (axis == 2) ? (size_t)N : N2;
+        const int variant = A.vmap[(((su < 0) ? 2 : 0) + ((sv < 0) ? 1 : 0)) * 2 + (axis != 0 ? 1 : 0)];
+        const PlaneInfo *__restrict__ planes = A.planes + (size_t)variant * A.nplanes;
+        const int u1 = u0 + 1, v1 = v0 + 1;
+
+        for (int i = tid; i < 2 * plane; i += SWEEP_THREADS) stg.st(i, 0.0);
+        __syncthreads();
+        if (tid == 0) {
+            size_t g0 = (size_t)p0 * strideP + (size_t)u0 * strideU + (size_t)v0;
+            double nHI = nhi[g0];
+            double path = 0.5 * A.dr;
+            double cdo = 0.0 + nHI * path;
+            stg.st(S + 1, cdo);
+            if (t == 0) {
+                double vol_ph = A.dr * A.dr * A.dr;
+                double ph, ht = 0.0;
+                cell_rates<HEAT>(A, flux, 0.0, cdo, vol_ph, nHI, ph, ht);
+                unsafeAtomicAdd(phi + g0, ph);
+                if (HEAT) unsafeAtomicAdd(heat + g0, ht);
+                if (write_cdh) cdh[g0] = cdo;
+            }
+        }
+        __syncthreads();
+
+        for (int n = 1; n <= nmax; n++) {
+            const int cur = (n & 1) * plane, prev = ((n - 1) & 1) * plane;
+            const PlaneInfo pi = planes[n];
+            const double alam = cinterp_alam(n);
+            const size_t baseP = (size_t)wrap(p0 + sp * n, N) * strideP;
+            const uint32_t *__restrict__ cab = A.cell_ab + pi.off;
+            const double *__restrict__ cpd = A.cell_pathdr + pi.off;
+            const double *__restrict__ cvol = A.cell_vol + pi.off;
+
+            auto cell = [&](int idx, auto with_rates) {
+                const uint32_t ab = cab[idx];
+                const double pathdr = cpd[idx];
+                const int a = (int)(ab >> 16), b = (int)(ab & 0xffffu);
+                const int uw = wrap(u0 + su * a, N), vw = wrap(v0 + sv * b, N);
+                const size_t g = baseP + (size_t)uw * strideU + (size_t)vw;
+                const double nHI = nhi[g];
+                const double c1 = stg.ld(prev + a * S + b);
+                const double c2 = stg.ld(prev + (a + 1) * S + b);
+                const double c3 = stg.ld(prev + a * S + b + 1);
+                const double c4 = stg.ld(prev + (a + 1) * S + b + 1);
+                const double cdh_in = cinterp_cd(n, a, b, su, sv, u1, v1, alam, c1, c2, c3, c4, A.sig, SQRT3_F32,
+                                                 SQRT2_F32);
+                const double cdo = cdh_in + nHI * pathdr;
+                stg.st(cur + (a + 1) * S + b + 1, cdo);
+                const bool ghost = (su < 0 && a == 0) || (sv < 0 && b == 0) || (axis >= 1 && b == n) ||
+                                   (axis == 2 && a == n);
+                if (!ghost) {
+                    if (write_cdh) cdh[g] = cdo;
+                    if (decltype(with_rates)::value) {
+                        if (!(cdh_in > max_coldensh)) {
+                            double ph, ht = 0.0;
+                            cell_rates<HEAT>(A, flux, cdh_in, cdo, cvol[idx], nHI, ph, ht);
+                            unsafeAtomicAdd(phi + g, ph);
+                            if (HEAT) unsafeAtomicAdd(heat + g, ht);
+                        }
+                    }
+                }
+            };
+            for (int idx = tid; idx < (int)pi.cntA; idx += SWEEP_THREADS) cell(idx, std::true_type{});
+            for (int idx = (int)pi.cntA + tid; idx < (int)pi.cntT; idx += SWEEP_THREADS) cell(idx, std::false_type{});
             __syncthreads();
         }
     }
@@ -369,6 +541,18 @@ __global__ void cinterp_test_kernel(double *out, const double *dens, int i0, int
     const int idx = threadIdx.z + blockDim.z * (threadIdx.y + blockDim.y * threadIdx.x);
     out[2 * idx] = cd;
     out[2 * idx + 1] = path;
+}
+
+// Bit-for-bit check of div_exact / rcp_exact / div_const against the compiler's IEEE division.
+// den[i] doubles as the constant divisor of div_const (its reciprocal is formed with `/`).
+__global__ void division_test_kernel(const double *num, const double *den, long long n, unsigned long long *cnt) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = num[i], d = den[i];
+    const double q = a / d, r = 1.0 / d;
+    if (__double_as_longlong(div_exact(a, d)) != __double_as_longlong(q)) atomicAdd(cnt + 0, 1ULL);
+    if (__double_as_longlong(rcp_exact(d)) != __double_as_longlong(r)) atomicAdd(cnt + 1, 1ULL);
+    if (__double_as_longlong(div_const(a, d, r)) != __double_as_longlong(q)) atomicAdd(cnt + 2, 1ULL);
 }
 
 }  // namespace asora

@@ -43,6 +43,9 @@ ABI = {
     "asora_visit_count": (C.c_int, [C.c_double, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "asora_last_sweep_ms": (C.c_int, [C.POINTER(C.c_float)]),
     "asora_last_launch_info": (C.c_int, [C.POINTER(C.c_int)] * 4),
+    "asora_set_option": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "asora_last_sweep_is_table_driven": (C.c_int, []),
+    "asora_test_division": (C.c_int, [_dp, _dp, C.c_longlong] + [C.POINTER(C.c_longlong)] * 3),
     "asora_last_error": (C.c_char_p, []),
 }
 
@@ -161,6 +164,20 @@ def visit_count(R, m1):
     return v.value, s.value
 
 
+def set_option(name, value):
+    _check(_lib.asora_set_option(name.encode(), int(value)))
+
+
+def test_division(num, den):
+    """(mismatches of div_exact, rcp_exact, div_const) against IEEE division, evaluated on the device."""
+    num = np.ascontiguousarray(num, dtype=np.float64)
+    den = np.ascontiguousarray(den, dtype=np.float64)
+    a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+    _check(_lib.asora_test_division(_f64(num, "num"), _f64(den, "den", num.size), num.size, C.byref(a), C.byref(b),
+                                    C.byref(c)))
+    return a.value, b.value, c.value
+
+
 def last_sweep_ms():
     ms = C.c_float()
     _check(_lib.asora_last_sweep_ms(C.byref(ms)))
@@ -170,4 +187,5 @@ def last_sweep_ms():
 def last_launch_info():
     g, b, l, s = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     _check(_lib.asora_last_launch_info(C.byref(g), C.byref(b), C.byref(l), C.byref(s)))
-    return dict(grid=g.value, block=b.value, lds_bytes=l.value, staging="lds" if s.value else "global")
+    return dict(grid=g.value, block=b.value, lds_bytes=l.value, staging="lds" if s.value else "global",
+                table_driven=bool(_lib.asora_last_sweep_is_table_driven()))

@@ -134,6 +134,36 @@ def test_cinterp_kat(golden_dir):
     assert np.array_equal(out[m], exp[m])
 
 
+def test_exact_division_helpers(asora):
+    """div_exact / rcp_exact / div_const are bit-identical to IEEE division on the ranges the path uses."""
+    rng = np.random.default_rng(5)
+    n = 1 << 20
+    num = np.concatenate([rng.uniform(0, 1, n) * 10.0 ** rng.uniform(-120, 80, n),       # fluxes, rates, weights
+                          rng.integers(0, 70000, n).astype(np.float64),                   # a^2 + b^2
+                          rng.uniform(-5, 30, n)])                                       # logtau - minlogtau
+    den = np.concatenate([rng.uniform(0.5, 2, n) * 10.0 ** rng.uniform(-30, 80, n),      # volumes, nHI, tau
+                          rng.integers(1, 300, n).astype(np.float64) ** 2,                # n^2
+                          np.full(n, 24.0 / 20000)])                                      # dlogtau
+    assert asora.test_division(num, den) == (0, 0, 0)
+
+
+@pytest.mark.parametrize("name", ["corner32", "lognormal48", "rcut7p3", "thick24"])
+def test_table_driven_equals_table_free_kernel(asora, golden_dir, name):
+    """The fast (geometry-table) kernel and the table-free kernel are the same arithmetic: for a single
+    source (one writer per cell, no atomic-order effect) their outputs are bit-identical."""
+    c = load_golden(golden_dir, name)
+    phi_t, cdh_t, _ = run_hip(asora, c, num_src=1)
+    assert asora.last_launch_info()["table_driven"]
+    asora.set_option("force_generic", 1)
+    try:
+        phi_g, cdh_g, _ = run_hip(asora, c, num_src=1)
+        assert not asora.last_launch_info()["table_driven"]
+    finally:
+        asora.set_option("force_generic", 0)
+    assert np.array_equal(cdh_t, cdh_g)
+    assert np.array_equal(phi_t, phi_g)
+
+
 def test_error_reporting(asora):
     """Errors surface as RuntimeError instead of being swallowed."""
     with pytest.raises(RuntimeError):
