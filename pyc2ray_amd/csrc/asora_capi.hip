@@ -69,6 +69,7 @@ struct State {
     int force_generic = 0;        // option "force_generic": always use the table-free kernel
     long long max_table_cells = 48LL << 20;  // option "max_table_cells": beyond this the generic kernel runs
     int last_tab = 0;
+    double *log10_table = nullptr;  // asora_log10.hpp table
     // staging scratch for planes that do not fit in LDS
     double *gscratch = nullptr;
     size_t gscratch_bytes = 0;
@@ -274,6 +275,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     A.cdhA = want_cdh ? S.cdhA : nullptr; A.cdhB = want_cdh ? S.cdhB : nullptr;
     A.src_pos = S.src_pos; A.src_flux = S.src_flux;
     A.thick = S.thick; A.thin = S.thin; A.hthick = S.hthick; A.hthin = S.hthin;
+    A.log10_table = S.log10_table;
     A.ntasks = (long long)asora::SECTORS * num_src;
     A.src_begin = 0;
     A.cdh_src = want_cdh ? num_src - 1 : -1;
@@ -292,8 +294,10 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     }
     A.S = wmax + 2;  // b = -1 guard .. wmax
     A.plane_elems = (wmax + 2) * A.S;
-    const size_t lds = 2 * (size_t)A.plane_elems * sizeof(double);
-    const bool use_lds = lds <= (size_t)S.max_lds;
+    const size_t lds_tab = asora::LOG10_TABLE_DOUBLES * sizeof(double);  // log10 table, always in LDS
+    const size_t lds_planes = 2 * (size_t)A.plane_elems * sizeof(double);
+    const bool use_lds = lds_planes + lds_tab <= (size_t)S.max_lds;
+    const size_t lds = (use_lds ? lds_planes : 0) + lds_tab;
 
     S.timed = false;
     int grid, rc = 0;
@@ -302,7 +306,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             grid = (int)std::min<long long>(A.ntasks, 0x7fffffffLL);
         } else {
             grid = (int)std::min<long long>(A.ntasks, (long long)S.num_cu * 4);
-            const size_t need = (size_t)grid * lds;
+            const size_t need = (size_t)grid * lds_planes;
             if (need > S.gscratch_bytes) {
                 if (S.gscratch) (void)hipFree(S.gscratch);
                 S.gscratch = nullptr;
@@ -326,15 +330,15 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         HIP_TRY(hipEventRecord(S.ev0, st));
         if (use_tab) {
             if (use_lds) rc = want_heat ? launch_sweep_tab<true, true>(A, grid, lds, st) : launch_sweep_tab<true, false>(A, grid, lds, st);
-            else rc = want_heat ? launch_sweep_tab<false, true>(A, grid, 0, st) : launch_sweep_tab<false, false>(A, grid, 0, st);
+            else rc = want_heat ? launch_sweep_tab<false, true>(A, grid, lds, st) : launch_sweep_tab<false, false>(A, grid, lds, st);
         } else {
             if (use_lds) rc = want_heat ? launch_sweep<true, true>(A, grid, lds, st) : launch_sweep<true, false>(A, grid, lds, st);
-            else rc = want_heat ? launch_sweep<false, true>(A, grid, 0, st) : launch_sweep<false, false>(A, grid, 0, st);
+            else rc = want_heat ? launch_sweep<false, true>(A, grid, lds, st) : launch_sweep<false, false>(A, grid, lds, st);
         }
         if (rc) return rc;
         HIP_TRY(hipEventRecord(S.ev1, st));
         S.timed = true;
-        S.last_grid = grid; S.last_block = asora::SWEEP_THREADS; S.last_lds = use_lds ? (int)lds : 0;
+        S.last_grid = grid; S.last_block = asora::SWEEP_THREADS; S.last_lds = (int)lds;
         S.last_is_lds = use_lds ? 1 : 0;
     }
 
@@ -411,6 +415,12 @@ int asora_device_init(int N, int num_src_par, int mpi_rank, int num_gpus) {
                         hipGetErrorString(e));
         }
     }
+    {
+        double tab[asora::LOG10_TABLE_DOUBLES];
+        asora::build_log10_table(tab);
+        HIP_TRY(hipMalloc(&S.log10_table, sizeof tab));
+        HIP_TRY(hipMemcpy(S.log10_table, tab, sizeof tab, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipEventCreate(&S.ev0));
     HIP_TRY(hipEventCreate(&S.ev1));
     S.init = true;
@@ -422,7 +432,7 @@ int asora_device_close(void) {
     (void)hipDeviceSynchronize();
     double **grids[] = {&S.n_dev, &S.x_dev, &S.nhiA, &S.nhiB, &S.phiA, &S.phiB, &S.heatA, &S.heatB, &S.cdhA,
                         &S.cdhB, &S.out0, &S.out1, &S.out2, &S.thin, &S.thick, &S.hthin, &S.hthick,
-                        &S.src_flux, &S.gscratch};
+                        &S.src_flux, &S.gscratch, &S.log10_table};
     for (double **g : grids) free_ptr(*g);
     if (S.src_pos) (void)hipFree(S.src_pos);
     S.src_pos = nullptr;

@@ -38,9 +38,14 @@
 
 #include <type_traits>
 
+#include "asora_log10.hpp"
+
 namespace asora {
 
-constexpr int SWEEP_THREADS = 256;
+#ifndef ASORA_SWEEP_THREADS
+#define ASORA_SWEEP_THREADS 256
+#endif
+constexpr int SWEEP_THREADS = ASORA_SWEEP_THREADS;
 constexpr int SECTORS = 24;
 constexpr double FOURPI = 4.0 * 3.14159265358979323846264338;  // raytracing.f90:47,457
 constexpr double SQRT3_F32 = 1.7320507764816284;                // (double)sqrtf(3.0f), raytracing.f90:608
@@ -63,6 +68,7 @@ struct SweepArgs {
     const int *src_pos;     // 0-based, interleaved
     const double *src_flux;
     const double *thick, *thin, *hthick, *hthin;  // padded tables
+    const double *log10_table;                    // LOG10_TABLE_DOUBLES doubles (asora_log10.hpp)
     double *gscratch;       // global staging (when LDS is too small), 2*plane_elems per block
     long long ntasks;       // 24 * number of sources of this launch
     int src_begin;          // first source of this launch
@@ -118,10 +124,30 @@ struct Lookup {
     double residual;
 };
 
-// photorates.f90:139-143 (index part of photo_lookuptable); log10 is the device library's.
+// log10 through the LDS-resident table of asora_log10.hpp (ASORA_OCML_LOG10: device library's log10)
+extern __shared__ double asora_smem[];
+struct Log10LDS {
+    int off;  // position of the log10 table in dynamic LDS (doubles)
+    __device__ __forceinline__ double operator()(double x) const {
+#ifdef ASORA_OCML_LOG10
+        return log10(x);
+#else
+        return log10_tab(x, asora_smem + off);
+#endif
+    }
+};
+__device__ __forceinline__ Log10LDS load_log10_table(const double *__restrict__ src, int off, int tid, int nthreads) {
+    for (int i = tid; i < LOG10_TABLE_DOUBLES; i += nthreads) asora_smem[off + i] = src[i];
+    __syncthreads();
+    Log10LDS l;
+    l.off = off;
+    return l;
+}
+
+// photorates.f90:139-143 (index part of photo_lookuptable)
 __device__ __forceinline__ Lookup table_index(double tau, double minlogtau, double dlogtau, double rdlogtau,
-                                              int num_tau) {
-    double logtau = log10(fmax(1.0e-20, tau));
+                                              int num_tau, Log10LDS lg) {
+    double logtau = lg(fmax(1.0e-20, tau));
     double real_i = fmin((double)num_tau, fmax(0.0, 1.0 + div_const(logtau - minlogtau, dlogtau, rdlogtau)));
     Lookup L;
     L.i0 = (int)real_i;
@@ -137,16 +163,16 @@ __device__ __forceinline__ double table_eval(const double *__restrict__ t, Looku
 
 // photorates.f90:62-125 followed by the division by nHI of raytracing.f90:531-532
 template <bool HEAT>
-__device__ __forceinline__ void cell_rates(const SweepArgs &A, double flux, double cdh_in, double cdh_out,
-                                           double vol_ph, double nHI, double &phi, double &heat) {
+__device__ __forceinline__ void cell_rates(const SweepArgs &A, Log10LDS lg, double flux, double cdh_in,
+                                           double cdh_out, double vol_ph, double nHI, double &phi, double &heat) {
     const double tau_photo_limit = (double)1.0e-7f;
     double tau_in = cdh_in * A.sig;
     double tau_out = cdh_out * A.sig;
     double prefact = div_exact(flux, vol_ph);
-    Lookup Lin = table_index(tau_in, A.minlogtau, A.dlogtau, A.rdlogtau, A.num_tau);
+    Lookup Lin = table_index(tau_in, A.minlogtau, A.dlogtau, A.rdlogtau, A.num_tau, lg);
     double phi_in = prefact * table_eval(A.thick, Lin);
     if (fabs(tau_out - tau_in) > tau_photo_limit) {
-        Lookup Lout = table_index(tau_out, A.minlogtau, A.dlogtau, A.rdlogtau, A.num_tau);
+        Lookup Lout = table_index(tau_out, A.minlogtau, A.dlogtau, A.rdlogtau, A.num_tau, lg);
         double phi_out = prefact * table_eval(A.thick, Lout);
         phi = phi_in - phi_out;
         if (HEAT) heat = prefact * (table_eval(A.hthick, Lin) - table_eval(A.hthick, Lout));
@@ -220,7 +246,6 @@ struct Stage {
     __device__ __forceinline__ double ld(int off) const;
     __device__ __forceinline__ void st(int off, double v) const;
 };
-extern __shared__ double asora_smem[];
 template <>
 __device__ __forceinline__ double Stage<true>::ld(int off) const { return asora_smem[off]; }
 template <>
@@ -245,6 +270,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
     const double max_coldensh = (double)2e30f;  // raytracing.f90:368
     const double R2 = A.R * A.R;
     const double dr2 = A.dr * A.dr;
+    const Log10LDS lg = load_log10_table(A.log10_table, LDS_STAGE ? 2 * plane : 0, tid, SWEEP_THREADS);
 
     for (long long task = blockIdx.x; task < A.ntasks; task += gridDim.x) {
         const int s = (int)(task / SECTORS);
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
             if (t == 0) {
                 double vol_ph = A.dr * A.dr * A.dr;
                 double ph, ht = 0.0;
-                cell_rates<HEAT>(A, flux, 0.0, cdo, vol_ph, nHI, ph, ht);
+                cell_rates<HEAT>(A, lg, flux, 0.0, cdo, vol_ph, nHI, ph, ht);
                 unsafeAtomicAdd(phi + g0, ph);
                 if (HEAT) unsafeAtomicAdd(heat + g0, ht);
                 if (write_cdh) cdh[g0] = cdo;
@@ -335,7 +361,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
                     if (write_cdh) cdh[g] = cdo;
                     if (!stop) {
                         double ph, ht = 0.0;
-                        cell_rates<HEAT>(A, flux, cdh_in, cdo, vol_ph, nHI, ph, ht);
+                        cell_rates<HEAT>(A, lg, flux, cdh_in, cdo, vol_ph, nHI, ph, ht);
                         unsafeAtomicAdd(phi + g, ph);
                         if (HEAT) unsafeAtomicAdd(heat + g, ht);
                     }
@@ -355,16 +381,111 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
 // density + rates) and B (outside: column density only), so wavefronts are fully populated and
 // never diverge on the sphere or the octahedron cut.
 // ------------------------------------------------------------------------------------------
+#ifndef ASORA_GROUP
+#define ASORA_GROUP 4
+#endif
+
+// Everything the cells of one plane of one task share.
+template <bool LDS_STAGE>
+struct PlaneCtx {
+    Stage<LDS_STAGE> stg;
+    Log10LDS lg;
+    const double *__restrict__ nhi;
+    double *__restrict__ phi;
+    double *__restrict__ heat;
+    double *__restrict__ cdh;  // null unless this task exports its column density
+    const uint32_t *__restrict__ cab;
+    const double *__restrict__ cpd;
+    const double *__restrict__ cvol;
+    size_t baseP, strideU;
+    double alam, flux;
+    int n, S, cur, prev, N, u0, v0, su, sv, axis;
+};
+
+// G cells per lane at once: all table loads, then all nHI loads and LDS reads, then the arithmetic.
+// Three dependent memory round trips per GROUP instead of per cell, and G independent f64
+// dependency chains for the scheduler to interleave.
+template <int G, bool RATES, bool HEAT, bool LDS_STAGE>
+__device__ __forceinline__ void process_cells(const SweepArgs &A, const PlaneCtx<LDS_STAGE> &C, int first, int stride,
+                                              int cnt) {
+    const double max_coldensh = (double)2e30f;  // raytracing.f90:368
+    int idx[G];
+    bool valid[G];
+    uint32_t ab[G];
+    double pathdr[G], vol[G], nHI[G], c1[G], c2[G], c3[G], c4[G];
+    size_t g[G];
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        const int i = first + k * stride;
+        valid[k] = i < cnt;
+        idx[k] = valid[k] ? i : cnt - 1;
+        ab[k] = C.cab[idx[k]];
+        pathdr[k] = C.cpd[idx[k]];
+        if (RATES) vol[k] = C.cvol[idx[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        const int a = (int)(ab[k] >> 16), b = (int)(ab[k] & 0xffffu);
+        const int uw = wrap(C.u0 + C.su * a, C.N), vw = wrap(C.v0 + C.sv * b, C.N);
+        g[k] = C.baseP + (size_t)uw * C.strideU + (size_t)vw;
+        nHI[k] = C.nhi[g[k]];
+        const int o = C.prev + a * C.S + b;
+        c1[k] = C.stg.ld(o);
+        c3[k] = C.stg.ld(o + 1);
+        c2[k] = C.stg.ld(o + C.S);
+        c4[k] = C.stg.ld(o + C.S + 1);
+    }
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        const int a = (int)(ab[k] >> 16), b = (int)(ab[k] & 0xffffu);
+        const double cdh_in = cinterp_cd(C.n, a, b, C.su, C.sv, C.u0 + 1, C.v0 + 1, C.alam, c1[k], c2[k], c3[k], c4[k],
+                                         A.sig, SQRT3_F32, SQRT2_F32);
+        const double cdo = cdh_in + nHI[k] * pathdr[k];
+        // ownership: reference tie order (z, y, x) and sign(0) = +1
+        const bool ghost = (C.su < 0 && a == 0) || (C.sv < 0 && b == 0) || (C.axis >= 1 && b == C.n) ||
+                           (C.axis == 2 && a == C.n);
+        if (valid[k]) {
+            C.stg.st(C.cur + (a + 1) * C.S + b + 1, cdo);
+            if (!ghost) {
+                if (C.cdh) C.cdh[g[k]] = cdo;
+                if (RATES) {
+                    if (!(cdh_in > max_coldensh)) {
+                        double ph, ht = 0.0;
+                        cell_rates<HEAT>(A, C.lg, C.flux, cdh_in, cdo, vol[k], nHI[k], ph, ht);
+                        unsafeAtomicAdd(C.phi + g[k], ph);
+                        if (HEAT) unsafeAtomicAdd(C.heat + g[k], ht);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// One dense cell list of a plane: 64-cell chunks dealt round-robin to the waves of the workgroup.
+template <bool RATES, bool HEAT, bool LDS_STAGE>
+__device__ __forceinline__ void process_list(const SweepArgs &A, const PlaneCtx<LDS_STAGE> &C, int cnt, int wave,
+                                             int lane) {
+    constexpr int NW = SWEEP_THREADS / 64;
+    const int nchunk = (cnt + 63) >> 6;
+    int c = wave;
+    for (; c + (ASORA_GROUP - 1) * NW < nchunk; c += ASORA_GROUP * NW)
+        process_cells<ASORA_GROUP, RATES, HEAT, LDS_STAGE>(A, C, c * 64 + lane, NW * 64, cnt);
+    for (; c < nchunk; c += NW) process_cells<1, RATES, HEAT, LDS_STAGE>(A, C, c * 64 + lane, NW * 64, cnt);
+}
+
 template <bool LDS_STAGE, bool HEAT>
 __global__ __launch_bounds__(SWEEP_THREADS) void sweep_tab_kernel(SweepArgs A) {
-    Stage<LDS_STAGE> stg;
-    stg.g = LDS_STAGE ? nullptr : A.gscratch + (size_t)blockIdx.x * 2 * (size_t)A.plane_elems;
+    PlaneCtx<LDS_STAGE> C;
+    C.stg.g = LDS_STAGE ? nullptr : A.gscratch + (size_t)blockIdx.x * 2 * (size_t)A.plane_elems;
     const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int S = A.S;
     const int plane = A.plane_elems;
     const int N = A.N;
     const size_t N2 = (size_t)N * N;
-    const double max_coldensh = (double)2e30f;  // raytracing.f90:368
+    C.lg = load_log10_table(A.log10_table, LDS_STAGE ? 2 * plane : 0, tid, SWEEP_THREADS);
+    C.S = S;
+    C.N = N;
 
     for (long long task = blockIdx.x; task < A.ntasks; task += gridDim.x) {
         const int s = (int)(task / SECTORS);
@@ -375,82 +496,58 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_tab_kernel(SweepArgs A) {
         const int su = (t & 2) ? -1 : 1;
         const int sv = (t & 1) ? -1 : 1;
         const int i0 = A.src_pos[3 * src + 0], j0 = A.src_pos[3 * src + 1], k0 = A.src_pos[3 * src + 2];
-        const double flux = A.src_flux[src];
         int p0, u0, v0;
         if (axis == 0) { p0 = k0; u0 = i0; v0 = j0; }
         else if (axis == 1) { p0 = j0; u0 = i0; v0 = k0; }
         else { p0 = i0; u0 = j0; v0 = k0; }
-        const double *__restrict__ nhi = (axis == 0) ? A.nhiB : A.nhiA;
-        double *__restrict__ phi = (axis == 0) ? A.phiB : A.phiA;
-        double *__restrict__ heat = (axis == 0) ? A.heatB : A.heatA;
-        double *__restrict__ cdh = (axis == 0) ? A.cdhB : A.cdhA;
-        const bool write_cdh = (src == A.cdh_src) && (cdh != nullptr);
+        C.flux = A.src_flux[src];
+        C.nhi = (axis == 0) ? A.nhiB : A.nhiA;
+        C.phi = (axis == 0) ? A.phiB : A.phiA;
+        C.heat = (axis == 0) ? A.heatB : A.heatA;
+        C.cdh = (src == A.cdh_src) ? ((axis == 0) ? A.cdhB : A.cdhA) : nullptr;
+        C.u0 = u0; C.v0 = v0; C.su = su; C.sv = sv; C.axis = axis;
         const int nmax = min(sp > 0 ? A.last_r : A.last_l, A.q_max);
         const size_t strideP = (axis == 2) ? N2 : (size_t)N;
-        const size_t strideU = (axis == 2) ? (size_t)N : N2;
+        C.strideU = (axis == 2) ? (size_t)N : N2;
         const int variant = A.vmap[(((su < 0) ? 2 : 0) + ((sv < 0) ? 1 : 0)) * 2 + (axis != 0 ? 1 : 0)];
         const PlaneInfo *__restrict__ planes = A.planes + (size_t)variant * A.nplanes;
-        const int u1 = u0 + 1, v1 = v0 + 1;
 
-        for (int i = tid; i < 2 * plane; i += SWEEP_THREADS) stg.st(i, 0.0);
+        // guard cells and never-written cells must read as 0 (their weights are 0 or O(eps))
+        for (int i = tid; i < 2 * plane; i += SWEEP_THREADS) C.stg.st(i, 0.0);
         __syncthreads();
         if (tid == 0) {
-            size_t g0 = (size_t)p0 * strideP + (size_t)u0 * strideU + (size_t)v0;
-            double nHI = nhi[g0];
+            // source cell, raytracing.f90:430-439
+            size_t g0 = (size_t)p0 * strideP + (size_t)u0 * C.strideU + (size_t)v0;
+            double nHI = C.nhi[g0];
             double path = 0.5 * A.dr;
             double cdo = 0.0 + nHI * path;
-            stg.st(S + 1, cdo);
+            C.stg.st(S + 1, cdo);
             if (t == 0) {
                 double vol_ph = A.dr * A.dr * A.dr;
                 double ph, ht = 0.0;
-                cell_rates<HEAT>(A, flux, 0.0, cdo, vol_ph, nHI, ph, ht);
-                unsafeAtomicAdd(phi + g0, ph);
-                if (HEAT) unsafeAtomicAdd(heat + g0, ht);
-                if (write_cdh) cdh[g0] = cdo;
+                cell_rates<HEAT>(A, C.lg, C.flux, 0.0, cdo, vol_ph, nHI, ph, ht);
+                unsafeAtomicAdd(C.phi + g0, ph);
+                if (HEAT) unsafeAtomicAdd(C.heat + g0, ht);
+                if (C.cdh) C.cdh[g0] = cdo;
             }
         }
         __syncthreads();
 
         for (int n = 1; n <= nmax; n++) {
-            const int cur = (n & 1) * plane, prev = ((n - 1) & 1) * plane;
             const PlaneInfo pi = planes[n];
-            const double alam = cinterp_alam(n);
-            const size_t baseP = (size_t)wrap(p0 + sp * n, N) * strideP;
-            const uint32_t *__restrict__ cab = A.cell_ab + pi.off;
-            const double *__restrict__ cpd = A.cell_pathdr + pi.off;
-            const double *__restrict__ cvol = A.cell_vol + pi.off;
-
-            auto cell = [&](int idx, auto with_rates) {
-                const uint32_t ab = cab[idx];
-                const double pathdr = cpd[idx];
-                const int a = (int)(ab >> 16), b = (int)(ab & 0xffffu);
-                const int uw = wrap(u0 + su * a, N), vw = wrap(v0 + sv * b, N);
-                const size_t g = baseP + (size_t)uw * strideU + (size_t)vw;
-                const double nHI = nhi[g];
-                const double c1 = stg.ld(prev + a * S + b);
-                const double c2 = stg.ld(prev + (a + 1) * S + b);
-                const double c3 = stg.ld(prev + a * S + b + 1);
-                const double c4 = stg.ld(prev + (a + 1) * S + b + 1);
-                const double cdh_in = cinterp_cd(n, a, b, su, sv, u1, v1, alam, c1, c2, c3, c4, A.sig, SQRT3_F32,
-                                                 SQRT2_F32);
-                const double cdo = cdh_in + nHI * pathdr;
-                stg.st(cur + (a + 1) * S + b + 1, cdo);
-                const bool ghost = (su < 0 && a == 0) || (sv < 0 && b == 0) || (axis >= 1 && b == n) ||
-                                   (axis == 2 && a == n);
-                if (!ghost) {
-                    if (write_cdh) cdh[g] = cdo;
-                    if (decltype(with_rates)::value) {
-                        if (!(cdh_in > max_coldensh)) {
-                            double ph, ht = 0.0;
-                            cell_rates<HEAT>(A, flux, cdh_in, cdo, cvol[idx], nHI, ph, ht);
-                            unsafeAtomicAdd(phi + g, ph);
-                            if (HEAT) unsafeAtomicAdd(heat + g, ht);
-                        }
-                    }
-                }
-            };
-            for (int idx = tid; idx < (int)pi.cntA; idx += SWEEP_THREADS) cell(idx, std::true_type{});
-            for (int idx = (int)pi.cntA + tid; idx < (int)pi.cntT; idx += SWEEP_THREADS) cell(idx, std::false_type{});
+            C.n = n;
+            C.cur = (n & 1) * plane;
+            C.prev = ((n - 1) & 1) * plane;
+            C.alam = cinterp_alam(n);
+            C.baseP = (size_t)wrap(p0 + sp * n, N) * strideP;
+            C.cab = A.cell_ab + pi.off;
+            C.cpd = A.cell_pathdr + pi.off;
+            C.cvol = A.cell_vol + pi.off;
+            process_list<true, HEAT, LDS_STAGE>(A, C, (int)pi.cntA, wave, lane);
+            C.cab += pi.cntA;
+            C.cpd += pi.cntA;
+            C.cvol += pi.cntA;
+            process_list<false, HEAT, LDS_STAGE>(A, C, (int)(pi.cntT - pi.cntA), wave, lane);
             __syncthreads();
         }
     }

@@ -17,7 +17,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libasora_hip.so")
+# ASORA_HIP_LIB: alternative build of the same library (A/B experiments); never a fallback
+LIB_PATH = os.environ.get("ASORA_HIP_LIB") or os.path.join(_HERE, "lib", "libasora_hip.so")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
