@@ -77,6 +77,27 @@ int asora_do_all_sources_dev(double R, double *coldensh_out_dev, double sig, dou
 /* Device-pointer upload of the density (device-to-device copy on `stream`). */
 int asora_density_from_device(const double *ndens_dev, int N, void *stream);
 
+/* ---- chemistry pass of the evolve loop ---------------------------------- */
+
+/* replaces chemistry.global_pass, src/c2ray/chemistry.f90:13-49 (f2py call at pyc2ray/evolve.py:326-340:
+ * conv_flag = global_pass(dt, ndens, temp, xh, xh_av, xh_intermed, phi_ion, clump, bh00, albpow, colh0,
+ * temph0, abu_c)).  HOST pointers to m1^3 doubles in the same flat C order as the raytracing grids
+ * (cells are independent, so the layout only has to be the same for all seven); xh_av and xh_intermed
+ * are updated in place, *conv_flag receives the number of non-converged cells. */
+int asora_global_pass(double dt, const double *ndens, const double *temp, const double *xh, double *xh_av,
+                      double *xh_intermed, const double *phi_ion, const double *clump, double bh00, double albpow,
+                      double colh0, double temph0, double abu_c, int m1, int *conv_flag);
+
+/* Same on DEVICE pointers, asynchronous on `stream` (hipStream_t).  Also forms the two sums the
+ * reference's convergence test takes on the host afterwards (sum(xh_intermed), sum(1 - xh_intermed),
+ * pyc2ray/evolve.py:350-351).  If any of conv_flag / sum_xh1 / sum_xh0 is non-NULL the call waits for
+ * the stream and stores the results there; with all three NULL it returns right after the launch. */
+int asora_global_pass_dev(double dt, const double *ndens_dev, const double *temp_dev, const double *xh_dev,
+                          double *xh_av_dev, double *xh_intermed_dev, const double *phi_ion_dev,
+                          const double *clump_dev, double bh00, double albpow, double colh0, double temph0,
+                          double abu_c, int m1, long long *conv_flag, double *sum_xh1, double *sum_xh0,
+                          void *stream);
+
 /* replaces asoratest::cinterp_gpu, src/asora/tests.cu:30-59 (Python module libasoratest.cinterp,
  * python_test_module.cu): for the 4x4x4 block of offsets (i,j,k) in [0,4)^3 from pos0, column density
  * and path from the short-characteristics interpolation on `dens` (N^3 doubles, used as the

@@ -5,6 +5,7 @@
 // minus the per-source N^3 column-density buffer (cdh_dev[M*N^3], memory.cu:75), which the sector
 // decomposition in asora_kernels.hpp does not need.
 #include "asora_kernels.hpp"
+#include "asora_chem.hpp"
 
 #include <algorithm>
 #include <array>
@@ -73,6 +74,9 @@ struct State {
     // staging scratch for planes that do not fit in LDS
     double *gscratch = nullptr;
     size_t gscratch_bytes = 0;
+    // chemistry pass: reduction results, and grid staging for the host-pointer entry point (lazy)
+    asora::ChemStats *chem_stats = nullptr;
+    double *chem_buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // timing / launch info
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -436,6 +440,9 @@ int asora_device_close(void) {
     for (double **g : grids) free_ptr(*g);
     if (S.src_pos) (void)hipFree(S.src_pos);
     S.src_pos = nullptr;
+    if (S.chem_stats) (void)hipFree(S.chem_stats);
+    S.chem_stats = nullptr;
+    for (double *&b : S.chem_buf) free_ptr(b);
     free_geometry();
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
@@ -528,6 +535,62 @@ int asora_do_all_sources_dev(double R, double *coldensh_out_dev, double sig, dou
                              double dlogtau, int num_tau, void *stream) {
     return do_all_sources_impl(R, coldensh_out_dev, sig, dr, xh_av_dev, phi_ion_dev, phi_heat_dev, num_src, m1,
                                minlogtau, dlogtau, num_tau, (hipStream_t)stream);
+}
+
+// ---- chemistry pass (asora_chem.hpp) ---------------------------------------------------------
+int asora_global_pass_dev(double dt, const double *ndens_dev, const double *temp_dev, const double *xh_dev,
+                          double *xh_av_dev, double *xh_intermed_dev, const double *phi_ion_dev,
+                          const double *clump_dev, double bh00, double albpow, double colh0, double temph0,
+                          double abu_c, int m1, long long *conv_flag, double *sum_xh1, double *sum_xh0,
+                          void *stream) {
+    if (!S.init) return fail(2, "asora_global_pass_dev: device not initialised (call asora_device_init)");
+    if (m1 < 1) return fail(9, "asora_global_pass_dev: bad mesh size %d", m1);
+    if (!ndens_dev || !temp_dev || !xh_dev || !xh_av_dev || !xh_intermed_dev || !phi_ion_dev || !clump_dev)
+        return fail(9, "asora_global_pass_dev: null grid pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (!S.chem_stats) HIP_TRY(hipMalloc(&S.chem_stats, sizeof(asora::ChemStats)));
+    HIP_TRY(hipMemsetAsync(S.chem_stats, 0, sizeof(asora::ChemStats), st));
+    asora::ChemArgs A;
+    A.ndens = ndens_dev; A.temp = temp_dev; A.xh = xh_dev; A.phi_ion = phi_ion_dev; A.clump = clump_dev;
+    A.xh_av = xh_av_dev; A.xh_intermed = xh_intermed_dev; A.stats = S.chem_stats;
+    A.ncell = (long long)m1 * m1 * m1;
+    A.dt = dt; A.bh00 = bh00; A.albpow = albpow; A.colh0 = colh0; A.temph0 = temph0; A.abu_c = abu_c;
+    const long long want = (A.ncell + asora::CHEM_THREADS - 1) / asora::CHEM_THREADS;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)S.num_cu * 16));
+    hipLaunchKernelGGL(asora::chemistry_kernel, dim3(grid), dim3(asora::CHEM_THREADS), 0, st, A);
+    HIP_TRY(hipGetLastError());
+    if (conv_flag || sum_xh1 || sum_xh0) {
+        asora::ChemStats h;
+        HIP_TRY(hipMemcpyAsync(&h, S.chem_stats, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (conv_flag) *conv_flag = (long long)h.conv_flag;
+        if (sum_xh1) *sum_xh1 = h.sum_xh1;
+        if (sum_xh0) *sum_xh0 = h.sum_xh0;
+    }
+    return 0;
+}
+
+int asora_global_pass(double dt, const double *ndens, const double *temp, const double *xh, double *xh_av,
+                      double *xh_intermed, const double *phi_ion, const double *clump, double bh00, double albpow,
+                      double colh0, double temph0, double abu_c, int m1, int *conv_flag) {
+    if (!S.init) return fail(2, "asora_global_pass: device not initialised (call asora_device_init)");
+    if (m1 != S.N) return fail(3, "asora_global_pass: m1=%d differs from device_init N=%d", m1, S.N);
+    if (!ndens || !temp || !xh || !xh_av || !xh_intermed || !phi_ion || !clump || !conv_flag)
+        return fail(9, "asora_global_pass: null pointer");
+    const size_t bytes = S.cells * sizeof(double);
+    for (double *&b : S.chem_buf)
+        if (int rc = alloc_grid(b)) return rc;
+    const double *src[7] = {ndens, temp, xh, xh_av, xh_intermed, phi_ion, clump};
+    for (int i = 0; i < 7; i++) HIP_TRY(hipMemcpy(S.chem_buf[i], src[i], bytes, hipMemcpyHostToDevice));
+    long long cf = 0;
+    if (int rc = asora_global_pass_dev(dt, S.chem_buf[0], S.chem_buf[1], S.chem_buf[2], S.chem_buf[3], S.chem_buf[4],
+                                       S.chem_buf[5], S.chem_buf[6], bh00, albpow, colh0, temph0, abu_c, m1, &cf,
+                                       nullptr, nullptr, nullptr))
+        return rc;
+    HIP_TRY(hipMemcpy(xh_av, S.chem_buf[3], bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(xh_intermed, S.chem_buf[4], bytes, hipMemcpyDeviceToHost));
+    *conv_flag = (int)cf;
+    return 0;
 }
 
 int asora_test_cinterp_ex(const int32_t pos0[3], const double *dens, int N, double sigma, int lo, int cnt,

@@ -1,0 +1,143 @@
+"""One evolve step of the ionised fraction -- the caller of the raytracing path.
+
+Mirror of the reference's ``pyc2ray/evolve.py:41-416`` (GPU branch): iterate
+``raytrace -> sum over ranks -> chemistry -> convergence test`` until the time-averaged ionised
+fraction has converged, then return ``(xh_new, phi_ion, coldensh_out)``.
+
+What is kept from the reference: the argument list, the flattening (C-order ``ravel`` +
+``astype(float64)``, ``:171-172``), the source wire format and contiguous sharding (``:173-189``), one
+upload of sources and density per step (``:192,201``), the convergence criterion
+``conv_criterion = min(int(convergence_fraction*N^3), (NumSrc-1)/3)`` (``:154``, with NumSrc the
+rank-local count exactly like the reference, ``:183``) and the two relative-change tests
+(``:350-373``).
+
+What is different (MI355X-first): all grids stay on the device for the whole step.  The raytrace
+writes phi_ion into a device tensor, the rank sum is ONE in-place RCCL all-reduce of that tensor
+(replaces the host ``Reduce`` + ``Bcast``, ``:309-317``), the chemistry pass is a HIP kernel on the
+same tensors (replaces the rank-0 Fortran ``global_pass`` and the three N^3 broadcasts that
+followed it, ``:326-340, :386-398``) and also returns the two sums of the convergence test.  Per
+iteration 24 bytes cross PCIe.  Every rank runs the (deterministic, per-cell) chemistry on
+identical inputs; the convergence decision is taken on rank 0 and broadcast, so ranks cannot diverge
+on it.
+
+``_evolve_loop`` is the host logic with the two device operations injected; the tests drive it
+with the CPU oracle to pin the loop itself (tests/test_evolve_host.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .sourceutils import format_sources, shard_sources
+
+__all__ = ["evolve3D", "conv_criterion"]
+
+
+def conv_criterion(convergence_fraction, num_cells, num_src):
+    """evolve.py:154"""
+    return min(int(convergence_fraction * num_cells), (num_src - 1) / 3)
+
+
+def _evolve_loop(raytrace, chemistry, num_cells, num_src, convergence_fraction, decide=None, max_iter=10000,
+                 history=None):
+    """The ``while not converged`` loop of evolve.py:232-401.
+
+    ``raytrace()`` must leave the all-rank phi_ion where ``chemistry`` finds it; ``chemistry()``
+    returns ``(conv_flag, sum(xh_intermed), sum(1 - xh_intermed))``.  ``decide(bool) -> bool`` makes the
+    decision collective (rank 0's value wins); identity for a single process.  Returns the number of
+    iterations."""
+    crit = conv_criterion(convergence_fraction, num_cells, num_src)
+    prev_sum_xh1_int = 2 * num_cells
+    prev_sum_xh0_int = 2 * num_cells
+    converged = False
+    niter = 0
+    while not converged:
+        niter += 1
+        raytrace()
+        conv_flag, sum_xh1_int, sum_xh0_int = chemistry()
+        if sum_xh1_int > 0.0:
+            rel_change_xh1 = abs((sum_xh1_int - prev_sum_xh1_int) / sum_xh1_int)
+        else:
+            rel_change_xh1 = 1.0
+        if sum_xh0_int > 0.0:
+            rel_change_xh0 = abs((sum_xh0_int - prev_sum_xh0_int) / sum_xh0_int)
+        else:
+            rel_change_xh0 = 1.0
+        converged = (conv_flag < crit) or ((rel_change_xh1 < convergence_fraction)
+                                           and (rel_change_xh0 < convergence_fraction))
+        if decide is not None:
+            converged = decide(converged)
+        if history is not None:
+            history.append(dict(conv_flag=int(conv_flag), rel_change_xh1=float(rel_change_xh1),
+                                rel_change_xh0=float(rel_change_xh0)))
+        prev_sum_xh1_int = sum_xh1_int
+        prev_sum_xh0_int = sum_xh0_int
+        if niter >= max_iter:
+            raise RuntimeError(f"evolve3D: no convergence after {niter} iterations")
+    return niter
+
+
+def evolve3D(dt, dr, src_flux, src_pos, use_gpu, max_subbox, subboxsize, loss_fraction, use_mpi, comm, rank,
+             nprocs, temp, ndens, xh, clump, photo_thin_table, photo_thick_table, minlogtau, dlogtau, R_max_LLS,
+             convergence_fraction, sig, bh00, albpow, colh0, temph0, abu_c, logfile="pyC2Ray.log", quiet=True,
+             history=None, want_coldens=True):
+    """Argument list of the reference (evolve.py:41-72).  ``use_gpu`` must be true.  ``use_mpi`` /
+    ``comm`` are ignored: the process group is ``torch.distributed``'s (if initialised), ``rank`` /
+    ``nprocs`` are taken from it.  Tables must have been uploaded with ``photo_table_to_device``.
+
+    Returns ``(xh_new, phi_ion, coldensh_out)`` as (N, N, N) float64 numpy arrays."""
+    import torch
+    import torch.distributed as dist
+
+    from . import asora_core
+    libasora = asora_core.libasora
+    if not use_gpu:
+        raise NotImplementedError("pyc2ray_amd implements the ASORA (GPU) branch of evolve3D only")
+    if not asora_core.cuda_is_init():
+        raise RuntimeError("GPU not initialized. Please initialize it by calling device_init(N)")
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank, nprocs = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
+
+    src_flux = np.asarray(src_flux)
+    src_pos = np.asarray(src_pos)
+    N = temp.shape[0]
+    NumCells = N * N * N
+    NumTau = photo_thin_table.shape[0]
+    lo, hi = shard_sources(src_flux.shape[0], rank, nprocs)
+    NumSrc = hi - lo
+    srcpos_flat, normflux_flat = format_sources(src_pos[:, lo:hi], src_flux[lo:hi])
+    libasora.source_data_to_device(srcpos_flat, normflux_flat, NumSrc)
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    up = lambda a: torch.from_numpy(np.ravel(a).astype("float64", copy=True)).to(dev)
+    ndens_t, temp_t, xh_t, clump_t = up(ndens), up(temp), up(xh), up(clump)
+    xh_av_t = xh_t.clone()
+    xh_intermed_t = xh_t.clone()
+    phi_t = torch.zeros(NumCells, dtype=torch.float64, device=dev)
+    cdh_t = torch.zeros(NumCells, dtype=torch.float64, device=dev) if want_coldens else None
+    stream = torch.cuda.current_stream().cuda_stream
+    libasora.density_from_device(ndens_t.data_ptr(), N, stream)
+
+    def raytrace():
+        libasora.do_all_sources_dev(R_max_LLS, cdh_t.data_ptr() if want_coldens else 0, sig, dr, xh_av_t.data_ptr(),
+                                    phi_t.data_ptr(), 0, NumSrc, N, minlogtau, dlogtau, NumTau, stream)
+        if distributed:
+            dist.all_reduce(phi_t)
+
+    def chemistry():
+        return libasora.global_pass_dev(dt, ndens_t.data_ptr(), temp_t.data_ptr(), xh_t.data_ptr(),
+                                        xh_av_t.data_ptr(), xh_intermed_t.data_ptr(), phi_t.data_ptr(),
+                                        clump_t.data_ptr(), bh00, albpow, colh0, temph0, abu_c, N, stream)
+
+    def decide(flag):
+        if not distributed:
+            return flag
+        t = torch.tensor([int(flag)], dtype=torch.int32, device=dev)
+        dist.broadcast(t, src=0)
+        return bool(t.item())
+
+    _evolve_loop(raytrace, chemistry, NumCells, NumSrc, convergence_fraction, decide, history=history)
+    shape = (N, N, N)
+    xh_new = xh_intermed_t.cpu().numpy().reshape(shape)
+    phi_ion = phi_t.cpu().numpy().reshape(shape)
+    coldensh_out = cdh_t.cpu().numpy().reshape(shape) if want_coldens else None
+    return xh_new, phi_ion, coldensh_out

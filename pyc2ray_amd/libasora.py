@@ -39,6 +39,9 @@ ABI = {
                                            C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                                            C.c_void_p]),
     "asora_density_from_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "asora_global_pass": (C.c_int, [C.c_double] + [_dp] * 7 + [C.c_double] * 5 + [C.c_int, C.POINTER(C.c_int)]),
+    "asora_global_pass_dev": (C.c_int, [C.c_double] + [C.c_void_p] * 7 + [C.c_double] * 5 +
+                              [C.c_int, C.POINTER(C.c_longlong), _dp, _dp, C.c_void_p]),
     "asora_test_cinterp": (C.c_int, [_ip, _dp, C.c_int, _dp, C.c_int]),
     "asora_test_cinterp_ex": (C.c_int, [_ip, _dp, C.c_int, C.c_double, C.c_int, C.c_int, _dp, C.c_int]),
     "asora_visit_count": (C.c_int, [C.c_double, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
@@ -51,11 +54,35 @@ ABI = {
 }
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so; if this shim
+    loaded the system one first, a later ``import torch`` (used for RCCL / device tensors) would bring a
+    second runtime into the process and see no GPU.  So when torch is installed but not yet imported,
+    its bundled runtime is loaded first and libasora_hip.so binds to it (same soname)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the ASORA path.")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in ABI.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
@@ -156,6 +183,39 @@ def do_all_sources_dev(R, coldensh_out_ptr, sig, dr, xh_av_ptr, phi_ion_ptr, phi
 
 def density_from_device(ndens_ptr, N, stream=0):
     _check(_lib.asora_density_from_device(C.c_void_p(ndens_ptr), int(N), C.c_void_p(stream or None)))
+
+
+def global_pass(dt, ndens, temp, xh, xh_av, xh_intermed, phi_ion, clump, bh00, albpow, colh0, temph0, abu_c):
+    """Chemistry pass on host grids: signature and semantics of the reference's f2py routine
+    ``libc2ray.chemistry.global_pass`` (chemistry.f90:13-49, called at evolve.py:326-340): ``xh_av`` and
+    ``xh_intermed`` are updated in place, the number of non-converged cells is returned.  All seven
+    grids must be float64 (N, N, N) arrays of one common memory layout (all C- or all F-contiguous)."""
+    grids = (ndens, temp, xh, xh_av, xh_intermed, phi_ion, clump)
+    N = grids[0].shape[0]
+    for g in grids:
+        if not isinstance(g, np.ndarray) or g.dtype != np.float64 or g.shape != (N, N, N):
+            raise TypeError("global_pass: grids must be float64 arrays of shape (N, N, N)")
+    if not (all(g.flags.c_contiguous for g in grids) or all(g.flags.f_contiguous for g in grids)):
+        raise ValueError("global_pass: all grids must share one contiguous layout")
+    conv = C.c_int(0)
+    ptr = [g.ctypes.data_as(_dp) for g in grids]
+    _check(_lib.asora_global_pass(float(dt), *ptr, float(bh00), float(albpow), float(colh0), float(temph0),
+                                  float(abu_c), int(N), C.byref(conv)))
+    return conv.value
+
+
+def global_pass_dev(dt, ndens_ptr, temp_ptr, xh_ptr, xh_av_ptr, xh_intermed_ptr, phi_ion_ptr, clump_ptr, bh00,
+                    albpow, colh0, temph0, abu_c, m1, stream=0, want_stats=True):
+    """Chemistry pass on device grids (integers = device addresses).  Returns
+    ``(conv_flag, sum(xh_intermed), sum(1 - xh_intermed))`` after waiting for the stream, or ``None``
+    (asynchronous) when ``want_stats`` is false."""
+    cf, s1, s0 = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
+    out = (C.byref(cf), C.byref(s1), C.byref(s0)) if want_stats else (None, None, None)
+    _check(_lib.asora_global_pass_dev(float(dt), *[C.c_void_p(p) for p in (ndens_ptr, temp_ptr, xh_ptr, xh_av_ptr,
+                                                                           xh_intermed_ptr, phi_ion_ptr, clump_ptr)],
+                                      float(bh00), float(albpow), float(colh0), float(temph0), float(abu_c), int(m1),
+                                      *out, C.c_void_p(stream or None)))
+    return (cf.value, s1.value, s0.value) if want_stats else None
 
 
 def visit_count(R, m1):

@@ -164,6 +164,43 @@ def reference_test_case(N=50, ns=10, R=15.0, numtau=20000):
                 pos=src_pos.reshape(ns, 3), flux=flux, pos_flat=src_pos)
 
 
+YEAR = 3.15576e7
+# chemistry constants of the reference's parameter files (examples/*/parameters.yml CGS / Abundances
+# sections, combined as in pyc2ray/c2ray_base.py:547-556)
+CHEM = dict(bh00=2.59e-13, albpow=-0.7, colh0=1.3e-8 * 0.83 * 1.0 / 13.598 ** 2, temph0=13.598 * 11604.51812,
+            abu_c=7.1e-7)
+
+
+def evolve_case(N=32, seed=5):
+    """One evolve step (SURVEY.md 8(c) golden (8)): three unequal sources switching on in an almost
+    neutral log-normal medium, dt = 1 Myr, cell of the single-source hackathon test (0.014 Mpc / 128),
+    T = 1e4 K, clumping 1, convergence_fraction 1e-4.  The ionisation fronts travel ~10 cells, so the
+    loop needs several raytrace/chemistry iterations."""
+    rng = np.random.default_rng(seed)
+    c = _base(N, 1.5 * N, 0.014 * MPC / 128, [[N // 2, N // 2, N // 2], [5, 27, 9], [22, 6, 25]], [10.0, 2.5, 0.4],
+              ndens=lognormal_density(N, seed, sigma_ln=0.5), xh=np.full((N, N, N), 1.2e-3))
+    c.update(CHEM)
+    c.update(dt=1e6 * YEAR, temp=np.full((N, N, N), 1e4), clump=np.ones((N, N, N)), convergence_fraction=1e-4)
+    return c
+
+
+def chemistry_case(N=24, seed=3):
+    """Random per-cell inputs for one chemistry pass covering neutral .. fully ionised cells, zero and
+    huge rates, temperatures 1e2 .. 1e5 K, clumping 1 .. 30, and a time average that differs from xh."""
+    rng = np.random.default_rng(seed)
+    sh = (N, N, N)
+    xh = 10.0 ** rng.uniform(-4, 0, sh)
+    xh[rng.random(sh) < 0.05] = 1.0 - 1e-9
+    xh_av = np.clip(xh * 10.0 ** rng.uniform(-0.3, 0.3, sh), 1e-14, 1.0 - 1e-12)
+    phi = 10.0 ** rng.uniform(-18, -9, sh)
+    phi[rng.random(sh) < 0.2] = 0.0
+    c = dict(N=N, dt=10.0 ** rng.uniform(12, 14.5), ndens=10.0 ** rng.uniform(-5, -1, sh),
+             temp=10.0 ** rng.uniform(2, 5, sh), xh=xh, xh_av=xh_av, xh_intermed=xh.copy(), phi_ion=phi,
+             clump=rng.uniform(1.0, 30.0, sh))
+    c.update(CHEM)
+    return c
+
+
 def run_oracle(oracle, c, heat=True, flux_mode=1, **kw):
     return oracle.do_all_sources(c["flux"], c["pos"], c["ndens"], c["xh"], c["sig"], c["dr"], c["thin"],
                                  c["thick"], c["minlogtau"], c["dlogtau"], c["R"],

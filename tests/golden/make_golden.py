@@ -95,26 +95,39 @@ def main():
     np.savez_compressed(os.path.join(OUT, "cinterp_kat.npz"), **kat)
     print("cinterp_kat.npz written")
 
-    if hasattr(cases, "evolve_case"):
-        make_evolve_golden(ref, port)
+    make_evolve_golden(ref, port)
 
 
 def make_evolve_golden(ref, port):
-    """(8) one full evolve step at 32^3: phi per iteration, xh_new, iteration count."""
-    from pyc2ray_amd.evolve import evolve3D_host  # host logic under test; oracle injected
+    """(8) one full evolve step at 32^3 and one stand-alone chemistry pass, from the reference."""
+    from evolve_host import evolve3D_host  # host loop of the product, oracle injected
 
     c = cases.evolve_case()
-    outs = {}
-    for tag, orc in (("ref", ref), ("port", port)):
-        outs[tag] = evolve3D_host(orc, **c)
-    a, b = outs["ref"], outs["port"]
-    assert a["niter"] == b["niter"]
+    a, b = evolve3D_host(ref, c), evolve3D_host(port, c)
+    assert a["niter"] == b["niter"] and a["conv_flags"] == b["conv_flags"]
     assert np.max(np.abs(a["xh_new"] - b["xh_new"])) <= 1e-14
-    np.savez_compressed(os.path.join(OUT, "evolve32.npz"), xh_new=a["xh_new"], phi_ion=a["phi_ion"],
-                        niter=a["niter"], conv_flags=np.asarray(a["conv_flags"]),
-                        phi_first=a["phi_history"][0])
-    print("evolve32.npz written: niter", a["niter"], "conv_flags", a["conv_flags"])
+    np.savez_compressed(os.path.join(OUT, "evolve32.npz"), xh_new=a["xh_new"], xh_av=a["xh_av"], phi_ion=a["phi_ion"],
+                        niter=a["niter"], conv_flags=np.asarray(a["conv_flags"]), phi_first=a["phi_first"])
+    print("evolve32.npz written: niter", a["niter"], "conv_flags", a["conv_flags"],
+          "mean xh", float(a["xh_new"].mean()))
+
+    c = cases.chemistry_case()
+    out = {}
+    for tag, orc in (("ref", ref), ("port", port)):
+        xa, xi = c["xh_av"].copy(), c["xh_intermed"].copy()
+        cf = orc.global_pass(c["dt"], c["ndens"], c["temp"], c["xh"], xa, xi, c["phi_ion"], c["clump"], c["bh00"],
+                             c["albpow"], c["colh0"], c["temph0"], c["abu_c"])
+        out[tag] = (cf, xa, xi)
+    assert out["ref"][0] == out["port"][0]
+    assert np.array_equal(out["ref"][1], out["port"][1]) and np.array_equal(out["ref"][2], out["port"][2])
+    np.savez_compressed(os.path.join(OUT, "chemistry24.npz"), conv_flag=out["ref"][0], xh_av=out["ref"][1],
+                        xh_intermed=out["ref"][2])
+    print("chemistry24.npz written: conv_flag", out["ref"][0])
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "evolve":
+        build_ref()
+        make_evolve_golden(RefOracle(), PortOracle())
+    else:
+        main()

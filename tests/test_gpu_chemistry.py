@@ -1,0 +1,94 @@
+"""GPU parity of the chemistry pass and of one full evolve step.
+
+Bars: xh_av / xh_intermed after one chemistry pass <= 1e-12 absolute against the compiled reference
+(the only differences are the device library's exp/pow, <= 2 ulp); conv_flag equal;
+xHII after a full evolve step <= 1e-8 (north_star), iteration count and per-iteration conv_flag equal.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+CHEM_KEYS = ("bh00", "albpow", "colh0", "temph0", "abu_c")
+GRID_KEYS = ("ndens", "temp", "xh", "xh_av", "xh_intermed", "phi_ion", "clump")
+
+
+@pytest.fixture(scope="module")
+def asora():
+    from pyc2ray_amd import libasora
+    return libasora
+
+
+def test_global_pass_host_vs_golden(asora, golden_dir, port_oracle):
+    g = np.load(os.path.join(golden_dir, "chemistry24.npz"))
+    c = cases.chemistry_case()
+    grids = [c[k].copy() for k in GRID_KEYS]
+    asora.device_init(c["N"], 8, 0, 1)
+    try:
+        cf = asora.global_pass(c["dt"], *grids, *[c[k] for k in CHEM_KEYS])
+    finally:
+        asora.device_close()
+    e_av = np.max(np.abs(grids[3] - g["xh_av"]))
+    e_in = np.max(np.abs(grids[4] - g["xh_intermed"]))
+    print(f"[chemistry24] conv_flag {cf} (ref {int(g['conv_flag'])})  max|d xh_av| {e_av:.2e}  max|d xh_intermed| {e_in:.2e}")
+    assert cf == int(g["conv_flag"])
+    assert e_av <= 1e-12 and e_in <= 1e-12
+    # inputs untouched
+    for k, a in zip(GRID_KEYS, grids):
+        if k not in ("xh_av", "xh_intermed"):
+            assert np.array_equal(a, c[k])
+
+
+def test_global_pass_dev_stats(asora, port_oracle):
+    """Device-pointer entry point: in-place update and the three reductions, 40^3 random cells."""
+    import torch
+    c = cases.chemistry_case(N=40, seed=17)
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(c[k].ravel().copy()).to(dev) for k in GRID_KEYS}
+    xa, xi = c["xh_av"].copy(), c["xh_intermed"].copy()
+    cf_ref = port_oracle.global_pass(c["dt"], c["ndens"], c["temp"], c["xh"], xa, xi, c["phi_ion"], c["clump"],
+                                     *[c[k] for k in CHEM_KEYS])
+    asora.device_init(c["N"], 8, 0, 1)
+    try:
+        cf, s1, s0 = asora.global_pass_dev(c["dt"], *[t[k].data_ptr() for k in GRID_KEYS], *[c[k] for k in CHEM_KEYS],
+                                           c["N"], torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    finally:
+        asora.device_close()
+    assert cf == cf_ref
+    assert np.max(np.abs(t["xh_av"].cpu().numpy() - xa.ravel())) <= 1e-12
+    assert np.max(np.abs(t["xh_intermed"].cpu().numpy() - xi.ravel())) <= 1e-12
+    assert abs(s1 - xi.sum()) <= 1e-9 * xi.sum()
+    assert abs(s0 - (1.0 - xi).sum()) <= 1e-9 * (1.0 - xi).sum()
+
+
+def test_evolve_step_vs_golden(golden_dir):
+    """One full evolve step through pyc2ray_amd.evolve.evolve3D (device-resident loop)."""
+    from pyc2ray_amd import asora_core
+    from pyc2ray_amd.evolve import evolve3D
+    g = np.load(os.path.join(golden_dir, "evolve32.npz"))
+    c = cases.evolve_case()
+    N = c["N"]
+    asora_core.device_init(N, 8, 0, 1)
+    try:
+        asora_core.photo_table_to_device(c["thin"], c["thick"])
+        hist = []
+        xh_new, phi, cdh = evolve3D(c["dt"], c["dr"], c["flux"], c["pos"].T, True, 0, 0, 0.0, False, None, 0, 1,
+                                    c["temp"], c["ndens"], c["xh"], c["clump"], c["thin"], c["thick"], c["minlogtau"],
+                                    c["dlogtau"], c["R"], c["convergence_fraction"], c["sig"],
+                                    *[c[k] for k in CHEM_KEYS], history=hist)
+    finally:
+        asora_core.device_close()
+    err = np.max(np.abs(xh_new - g["xh_new"]))
+    m = g["phi_ion"] > 0
+    rel_phi = np.max(np.abs(phi[m] / g["phi_ion"][m] - 1.0))
+    print(f"[evolve32] niter {len(hist)} (ref {int(g['niter'])})  max|d xHII| {err:.2e}  phi max_rel {rel_phi:.2e}")
+    assert len(hist) == int(g["niter"])
+    assert [h["conv_flag"] for h in hist] == list(g["conv_flags"])
+    assert err <= 1e-8  # north_star bar; typically ~1e-13
+    assert rel_phi <= 1e-8  # phi of the last iteration, computed from an xh_av that differs by ~1e-13
+    assert cdh.shape == (N, N, N) and np.all(np.isfinite(cdh))
