@@ -124,6 +124,9 @@ def main():
     xh_t = torch.from_numpy(inp["xh"].ravel()).to(dev)
     phi_t = torch.zeros(N ** 3, dtype=torch.float64, device=dev)
 
+    for kv in filter(None, os.environ.get("ASORA_OPTIONS", "").split(",")):  # tuning experiments: name=value,...
+        k, v = kv.split("=")
+        asora.set_option(k, int(v))
     asora.device_init(N, 64, local_rank, torch.cuda.device_count())
     asora.photo_table_to_device(np.ascontiguousarray(inp["thin"]), np.ascontiguousarray(inp["thick"]),
                                 inp["thin"].shape[0])

@@ -67,6 +67,7 @@ struct State {
     int geo_N = 0, geo_nplanes = 0, geo_vmap[8] = {0};
     double geo_R = -1.0, geo_dr = -1.0;
     bool geo_valid = false;
+    int lds_pad = 0;              // option "lds_pad": extra dynamic LDS per workgroup (occupancy experiments)
     int force_generic = 0;        // option "force_generic": always use the table-free kernel
     long long max_table_cells = 48LL << 20;  // option "max_table_cells": beyond this the generic kernel runs
     int last_tab = 0;
@@ -299,9 +300,15 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     A.S = wmax + 2;  // b = -1 guard .. wmax
     A.plane_elems = (wmax + 2) * A.S;
     const size_t lds_tab = asora::LOG10_TABLE_DOUBLES * sizeof(double);  // log10 table, always in LDS
-    const size_t lds_planes = 2 * (size_t)A.plane_elems * sizeof(double);
-    const bool use_lds = lds_planes + lds_tab <= (size_t)S.max_lds;
-    const size_t lds = (use_lds ? lds_planes : 0) + lds_tab;
+    const int nmaxmax = std::min(std::max(A.last_l, A.last_r), A.q_max);
+    // the table-driven kernel needs 32-bit cell offsets and 16-bit in-plane coordinates
+    const bool use_tab = !S.force_generic && S.cells < (1ULL << 28) && N < 65536 &&
+                         8 * geometry_cells_per_variant(A.q_max, std::max(A.last_l, A.last_r), nmaxmax) <=
+                             S.max_table_cells;
+    // staged planes: ONE for the table-driven kernel (in-place update), TWO for the table-free one
+    const size_t lds_planes = (use_tab ? 1 : 2) * (size_t)A.plane_elems * sizeof(double);
+    const bool use_lds = lds_planes + lds_tab + (size_t)S.lds_pad <= (size_t)S.max_lds;
+    const size_t lds = (use_lds ? lds_planes : 0) + lds_tab + (size_t)S.lds_pad;
 
     S.timed = false;
     int grid, rc = 0;
@@ -320,10 +327,6 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             }
             A.gscratch = S.gscratch;
         }
-        const int nmaxmax = std::min(std::max(A.last_l, A.last_r), A.q_max);
-        const bool use_tab = !S.force_generic && N < 65536 &&
-                             8 * geometry_cells_per_variant(A.q_max, std::max(A.last_l, A.last_r), nmaxmax) <=
-                                 S.max_table_cells;
         if (use_tab) {
             if (int rc2 = build_geometry(N, R, dr, A.q_max, A.last_l, A.last_r, st)) return rc2;
             A.planes = S.planes_dev; A.cell_ab = S.cell_ab_dev; A.cell_pathdr = S.cell_pathdr_dev;
@@ -447,7 +450,7 @@ int asora_device_close(void) {
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     State fresh;  // options and the last launch record survive a close
-    fresh.force_generic = S.force_generic; fresh.max_table_cells = S.max_table_cells;
+    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.max_table_cells = S.max_table_cells;
     fresh.last_tab = S.last_tab; fresh.last_grid = S.last_grid; fresh.last_block = S.last_block;
     fresh.last_lds = S.last_lds; fresh.last_is_lds = S.last_is_lds;
     S = fresh;
@@ -665,6 +668,7 @@ int asora_set_option(const char *name, long long value) {
     if (!name) return fail(9, "asora_set_option: null name");
     if (!std::strcmp(name, "force_generic")) S.force_generic = value != 0;
     else if (!std::strcmp(name, "max_table_cells")) S.max_table_cells = value;
+    else if (!std::strcmp(name, "lds_pad")) S.lds_pad = (int)value;
     else return fail(12, "asora_set_option: unknown option '%s'", name);
     return 0;
 }

@@ -378,11 +378,26 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
 // in the octahedron/box, the oracle's exact R-sphere predicate, path*dr and vol_ph -- is computed
 // once per call on the host with the same IEEE operations (build_geometry in asora_capi.hip) and
 // streamed from L2.  Per plane the cells come as two dense lists: A (inside the R sphere: column
-// density + rates) and B (outside: column density only), so wavefronts are fully populated and
-// never diverge on the sphere or the octahedron cut.
+// density + rates) and B (outside: column density only), cut into 64-cell chunks, so wavefronts
+// are fully populated and never diverge on the sphere or the octahedron cut.
+//
+// ONE plane of column densities is staged (in LDS), updated IN PLACE: occupancy on this kernel is
+// worth more than anything else (measured: 3 -> 2 workgroups per CU costs 29 %), and a single
+// plane halves the LDS footprint.  In-place is safe because of the processing order.  A plane is
+// worked off in PHASES of up to NW*P chunks; within a phase every wave first computes its cells
+// from the old values (results stay in registers), then -- after a barrier -- all waves write.
+// Across phases chunks are taken in DECREASING order: list B from its last chunk down, then list A
+// from its last chunk down.  Cell (a, b) reads the old values at (a-1,b-1), (a,b-1), (a-1,b), (a,b):
+// all at row-major positions <= its own, and for an A cell all inside list A (the sphere's row
+// extent shrinks with a), so nothing it reads has been overwritten by an earlier phase.
+// Positions a plane does not write (beyond the octahedron cut) are never read later with
+// non-zero weight; never-written positions and the guard row/column read as 0.
 // ------------------------------------------------------------------------------------------
 #ifndef ASORA_GROUP
-#define ASORA_GROUP 4
+#define ASORA_GROUP 1
+#endif
+#ifndef ASORA_PHASE_CHUNKS
+#define ASORA_PHASE_CHUNKS 4
 #endif
 
 // Everything the cells of one plane of one task share.
@@ -394,42 +409,48 @@ struct PlaneCtx {
     double *__restrict__ phi;
     double *__restrict__ heat;
     double *__restrict__ cdh;  // null unless this task exports its column density
-    const uint32_t *__restrict__ cab;
+    const uint32_t *__restrict__ cab;  // tables of the current plane
     const double *__restrict__ cpd;
     const double *__restrict__ cvol;
-    size_t baseP, strideU;
+    uint32_t baseP, strideU;
     double alam, flux;
-    int n, S, cur, prev, N, u0, v0, su, sv, axis;
+    int n, S, N, u0, v0, su, sv, axis;
+    int cntA, cntT, nchunkA, nchunkB;
 };
 
-// G cells per lane at once: all table loads, then all nHI loads and LDS reads, then the arithmetic.
-// Three dependent memory round trips per GROUP instead of per cell, and G independent f64
-// dependency chains for the scheduler to interleave.
-template <int G, bool RATES, bool HEAT, bool LDS_STAGE>
-__device__ __forceinline__ void process_cells(const SweepArgs &A, const PlaneCtx<LDS_STAGE> &C, int first, int stride,
-                                              int cnt) {
+// G chunks of one wave (sequence positions j, j + NW, ...): all table loads, then all nHI loads and
+// LDS reads, then the arithmetic.  Three dependent memory round trips per GROUP instead of per
+// cell.  Results (new column density + LDS position) are returned for the deferred write.
+template <int G, bool HEAT, bool LDS_STAGE>
+__device__ __forceinline__ void process_group(const SweepArgs &A, const PlaneCtx<LDS_STAGE> &C, int j, int lane,
+                                              double *cdo_out, int *woff_out) {
+    constexpr int NW = SWEEP_THREADS / 64;
     const double max_coldensh = (double)2e30f;  // raytracing.f90:368
-    int idx[G];
-    bool valid[G];
-    uint32_t ab[G];
+    const int nchunk = C.nchunkA + C.nchunkB;
+    bool valid[G], isA[G];
+    uint32_t idx[G], ab[G], g[G];
     double pathdr[G], vol[G], nHI[G], c1[G], c2[G], c3[G], c4[G];
-    size_t g[G];
 #pragma unroll
     for (int k = 0; k < G; k++) {
-        const int i = first + k * stride;
-        valid[k] = i < cnt;
-        idx[k] = valid[k] ? i : cnt - 1;
+        const int jj = j + k * NW;  // wave-uniform
+        // decreasing order: B chunks from the last down, then A chunks from the last down
+        isA[k] = jj >= C.nchunkB;
+        const int c = isA[k] ? C.nchunkA - 1 - (jj - C.nchunkB) : C.nchunkB - 1 - jj;
+        const int i = isA[k] ? c * 64 + lane : C.cntA + c * 64 + lane;
+        const int lim = isA[k] ? C.cntA : C.cntT;
+        valid[k] = (jj < nchunk) && (i < lim);
+        idx[k] = (uint32_t)(valid[k] ? i : 0);
         ab[k] = C.cab[idx[k]];
         pathdr[k] = C.cpd[idx[k]];
-        if (RATES) vol[k] = C.cvol[idx[k]];
+        vol[k] = C.cvol[idx[k]];
     }
 #pragma unroll
     for (int k = 0; k < G; k++) {
         const int a = (int)(ab[k] >> 16), b = (int)(ab[k] & 0xffffu);
         const int uw = wrap(C.u0 + C.su * a, C.N), vw = wrap(C.v0 + C.sv * b, C.N);
-        g[k] = C.baseP + (size_t)uw * C.strideU + (size_t)vw;
+        g[k] = C.baseP + (uint32_t)uw * C.strideU + (uint32_t)vw;
         nHI[k] = C.nhi[g[k]];
-        const int o = C.prev + a * C.S + b;
+        const int o = a * C.S + b;
         c1[k] = C.stg.ld(o);
         c3[k] = C.stg.ld(o + 1);
         c2[k] = C.stg.ld(o + C.S);
@@ -444,46 +465,47 @@ __device__ __forceinline__ void process_cells(const SweepArgs &A, const PlaneCtx
         // ownership: reference tie order (z, y, x) and sign(0) = +1
         const bool ghost = (C.su < 0 && a == 0) || (C.sv < 0 && b == 0) || (C.axis >= 1 && b == C.n) ||
                            (C.axis == 2 && a == C.n);
-        if (valid[k]) {
-            C.stg.st(C.cur + (a + 1) * C.S + b + 1, cdo);
-            if (!ghost) {
-                if (C.cdh) C.cdh[g[k]] = cdo;
-                if (RATES) {
-                    if (!(cdh_in > max_coldensh)) {
-                        double ph, ht = 0.0;
-                        cell_rates<HEAT>(A, C.lg, C.flux, cdh_in, cdo, vol[k], nHI[k], ph, ht);
-                        unsafeAtomicAdd(C.phi + g[k], ph);
-                        if (HEAT) unsafeAtomicAdd(C.heat + g[k], ht);
-                    }
+        cdo_out[k] = cdo;
+        woff_out[k] = valid[k] ? (a + 1) * C.S + b + 1 : -1;
+        if (valid[k] && !ghost) {
+            if (C.cdh) C.cdh[g[k]] = cdo;
+            if (isA[k]) {
+#ifdef ASORA_ABL_NORATES
+                if (cdh_in == 1.2345e300) {  // ablation build: column densities only
+#else
+                if (!(cdh_in > max_coldensh)) {
+#endif
+                    double ph, ht = 0.0;
+                    cell_rates<HEAT>(A, C.lg, C.flux, cdh_in, cdo, vol[k], nHI[k], ph, ht);
+#ifdef ASORA_ABL_NOATOMIC
+                    if (ph == 1.2345e300)  // ablation build: rates computed, (almost) never added
+#endif
+                    unsafeAtomicAdd(C.phi + g[k], ph);
+                    if (HEAT) unsafeAtomicAdd(C.heat + g[k], ht);
                 }
             }
         }
     }
 }
 
-// One dense cell list of a plane: 64-cell chunks dealt round-robin to the waves of the workgroup.
-template <bool RATES, bool HEAT, bool LDS_STAGE>
-__device__ __forceinline__ void process_list(const SweepArgs &A, const PlaneCtx<LDS_STAGE> &C, int cnt, int wave,
-                                             int lane) {
-    constexpr int NW = SWEEP_THREADS / 64;
-    const int nchunk = (cnt + 63) >> 6;
-    int c = wave;
-    for (; c + (ASORA_GROUP - 1) * NW < nchunk; c += ASORA_GROUP * NW)
-        process_cells<ASORA_GROUP, RATES, HEAT, LDS_STAGE>(A, C, c * 64 + lane, NW * 64, cnt);
-    for (; c < nchunk; c += NW) process_cells<1, RATES, HEAT, LDS_STAGE>(A, C, c * 64 + lane, NW * 64, cnt);
-}
-
+// register budget: 5 waves per SIMD (<= 96 VGPRs; measured faster than 4 or 6 on the 256^3 / R = 60 sweep)
+#ifndef ASORA_WAVES_PER_EU
+#define ASORA_WAVES_PER_EU 5
+#endif
 template <bool LDS_STAGE, bool HEAT>
-__global__ __launch_bounds__(SWEEP_THREADS) void sweep_tab_kernel(SweepArgs A) {
+__global__ __launch_bounds__(SWEEP_THREADS) __attribute__((amdgpu_waves_per_eu(ASORA_WAVES_PER_EU, ASORA_WAVES_PER_EU)))
+void sweep_tab_kernel(SweepArgs A) {
+    constexpr int G = ASORA_GROUP, P = ASORA_PHASE_CHUNKS, NW = SWEEP_THREADS / 64;
+    static_assert(P % G == 0, "a phase is a whole number of groups");
     PlaneCtx<LDS_STAGE> C;
-    C.stg.g = LDS_STAGE ? nullptr : A.gscratch + (size_t)blockIdx.x * 2 * (size_t)A.plane_elems;
+    C.stg.g = LDS_STAGE ? nullptr : A.gscratch + (size_t)blockIdx.x * (size_t)A.plane_elems;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int S = A.S;
     const int plane = A.plane_elems;
     const int N = A.N;
-    const size_t N2 = (size_t)N * N;
-    C.lg = load_log10_table(A.log10_table, LDS_STAGE ? 2 * plane : 0, tid, SWEEP_THREADS);
+    const uint32_t N2 = (uint32_t)N * (uint32_t)N;
+    C.lg = load_log10_table(A.log10_table, LDS_STAGE ? plane : 0, tid, SWEEP_THREADS);
     C.S = S;
     C.N = N;
 
@@ -491,7 +513,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_tab_kernel(SweepArgs A) {
         const int s = (int)(task / SECTORS);
         const int t = (int)(task - (long long)s * SECTORS);
         const int src = A.src_begin + s;
-        const int axis = t >> 3;
+        const int axis = t >> 3;  // 0: z-dominant, 1: y-dominant, 2: x-dominant
         const int sp = (t & 4) ? -1 : 1;
         const int su = (t & 2) ? -1 : 1;
         const int sv = (t & 1) ? -1 : 1;
@@ -507,17 +529,17 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_tab_kernel(SweepArgs A) {
         C.cdh = (src == A.cdh_src) ? ((axis == 0) ? A.cdhB : A.cdhA) : nullptr;
         C.u0 = u0; C.v0 = v0; C.su = su; C.sv = sv; C.axis = axis;
         const int nmax = min(sp > 0 ? A.last_r : A.last_l, A.q_max);
-        const size_t strideP = (axis == 2) ? N2 : (size_t)N;
-        C.strideU = (axis == 2) ? (size_t)N : N2;
+        const uint32_t strideP = (axis == 2) ? N2 : (uint32_t)N;
+        C.strideU = (axis == 2) ? (uint32_t)N : N2;
         const int variant = A.vmap[(((su < 0) ? 2 : 0) + ((sv < 0) ? 1 : 0)) * 2 + (axis != 0 ? 1 : 0)];
         const PlaneInfo *__restrict__ planes = A.planes + (size_t)variant * A.nplanes;
 
         // guard cells and never-written cells must read as 0 (their weights are 0 or O(eps))
-        for (int i = tid; i < 2 * plane; i += SWEEP_THREADS) C.stg.st(i, 0.0);
+        for (int i = tid; i < plane; i += SWEEP_THREADS) C.stg.st(i, 0.0);
         __syncthreads();
         if (tid == 0) {
             // source cell, raytracing.f90:430-439
-            size_t g0 = (size_t)p0 * strideP + (size_t)u0 * C.strideU + (size_t)v0;
+            const uint32_t g0 = (uint32_t)p0 * strideP + (uint32_t)u0 * C.strideU + (uint32_t)v0;
             double nHI = C.nhi[g0];
             double path = 0.5 * A.dr;
             double cdo = 0.0 + nHI * path;
@@ -536,19 +558,35 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_tab_kernel(SweepArgs A) {
         for (int n = 1; n <= nmax; n++) {
             const PlaneInfo pi = planes[n];
             C.n = n;
-            C.cur = (n & 1) * plane;
-            C.prev = ((n - 1) & 1) * plane;
             C.alam = cinterp_alam(n);
-            C.baseP = (size_t)wrap(p0 + sp * n, N) * strideP;
+            C.baseP = (uint32_t)wrap(p0 + sp * n, N) * strideP;
             C.cab = A.cell_ab + pi.off;
             C.cpd = A.cell_pathdr + pi.off;
             C.cvol = A.cell_vol + pi.off;
-            process_list<true, HEAT, LDS_STAGE>(A, C, (int)pi.cntA, wave, lane);
-            C.cab += pi.cntA;
-            C.cpd += pi.cntA;
-            C.cvol += pi.cntA;
-            process_list<false, HEAT, LDS_STAGE>(A, C, (int)(pi.cntT - pi.cntA), wave, lane);
-            __syncthreads();
+            C.cntA = (int)pi.cntA;
+            C.cntT = (int)pi.cntT;
+            C.nchunkA = (C.cntA + 63) >> 6;
+            C.nchunkB = (C.cntT - C.cntA + 63) >> 6;
+            const int nchunk = C.nchunkA + C.nchunkB;
+            for (int jbase = 0; jbase < nchunk; jbase += NW * P) {
+                double cdo[P];
+                int woff[P];
+#pragma unroll
+                for (int q = 0; q < P; q += G) {
+                    const int j = jbase + wave + q * NW;
+                    if (j < nchunk) {
+                        process_group<G, HEAT, LDS_STAGE>(A, C, j, lane, cdo + q, woff + q);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < G; k++) { cdo[q + k] = 0.0; woff[q + k] = -1; }
+                    }
+                }
+                __syncthreads();  // every wave has read the old values it needs
+#pragma unroll
+                for (int q = 0; q < P; q++)
+                    if (woff[q] >= 0) C.stg.st(woff[q], cdo[q]);
+                __syncthreads();  // new values visible
+            }
         }
     }
 }
