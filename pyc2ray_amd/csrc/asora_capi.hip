@@ -62,9 +62,9 @@ struct State {
     int num_src = 0;
     // geometry tables of the table-driven sweep (cached per (N, R, dr))
     asora::PlaneInfo *planes_dev = nullptr;
-    uint32_t *cell_ab_dev = nullptr;
-    double *cell_pathdr_dev = nullptr, *cell_vol_dev = nullptr;
-    int geo_N = 0, geo_nplanes = 0, geo_vmap[8] = {0};
+    uint2 *cell_meta_dev = nullptr;
+    double2 *cell_geo_dev = nullptr;
+    int geo_N = 0, geo_nplanes = 0, geo_entries = 0, geo_vmap[8] = {0};
     double geo_R = -1.0, geo_dr = -1.0;
     bool geo_valid = false;
     int lds_pad = 0;              // option "lds_pad": extra dynamic LDS per workgroup (occupancy experiments)
@@ -122,15 +122,18 @@ int compute_q_max(double R, int m1) {
 // variant and each plane n: list A = cells with dist2/dr2 <= R2 evaluated EXACTLY as the oracle does
 // (raytracing.f90:448-451,474: xs = dr*real(di), dist2 = xs*xs + ys*ys + zs*zs in x,y,z order,
 // no contraction -- this file is compiled with -ffp-contract=off for the host too), list B = the
-// other cells of octahedron ∩ box.  path = sqrt((a^2+b^2)/n^2 + 1) (raytracing.f90:710), stored
-// as path*dr, and vol_ph = dist2*path*dr*4pi (raytracing.f90:457).
+// other cells of octahedron ∩ box, both in row-major (a, b) order.  Per cell: path = sqrt((a^2+b^2)/n^2 + 1)
+// (raytracing.f90:710) stored as path*dr, vol_ph = dist2*path*dr*4pi (raytracing.f90:457), the
+// ownership flags, and its positions in the variant's staging layout: the packed union of all
+// planes' domains, row a holding one leading guard (b = -1) and b = 0 .. rowlen[a]-1, preceded by
+// a guard row (a = -1).  Every position a cell reads lies inside that union (smaller coordinates
+// of a member are members), so no trailing guards are needed.
 // ------------------------------------------------------------------------------------------
 void free_geometry() {
     if (S.planes_dev) (void)hipFree(S.planes_dev);
-    if (S.cell_ab_dev) (void)hipFree(S.cell_ab_dev);
-    if (S.cell_pathdr_dev) (void)hipFree(S.cell_pathdr_dev);
-    if (S.cell_vol_dev) (void)hipFree(S.cell_vol_dev);
-    S.planes_dev = nullptr; S.cell_ab_dev = nullptr; S.cell_pathdr_dev = nullptr; S.cell_vol_dev = nullptr;
+    if (S.cell_meta_dev) (void)hipFree(S.cell_meta_dev);
+    if (S.cell_geo_dev) (void)hipFree(S.cell_geo_dev);
+    S.planes_dev = nullptr; S.cell_meta_dev = nullptr; S.cell_geo_dev = nullptr;
     S.geo_valid = false;
 }
 
@@ -143,19 +146,43 @@ long long geometry_cells_per_variant(int q_max, int lim, int nmaxmax) {
     return c;
 }
 
+// widest in-plane extent the octahedron and the box allow
+int plane_extent(int q_max, int last_l, int last_r) {
+    const int lim = std::max(last_l, last_r), nmaxmax = std::min(lim, q_max);
+    int cap = 0;
+    for (int n = 0; n <= nmaxmax; n++) cap = std::max(cap, std::min(std::min(n, lim), q_max - n));
+    return cap;
+}
+
+// staged entries of the packed layout for in-plane limits (LU, LV); fills rowoff (a + 1 -> first position)
+int packed_layout(int q_max, int nmaxmax, int LU, int LV, std::vector<int> &rowoff) {
+    std::vector<int> rowlen(LU + 1, 0);
+    for (int n = 0; n <= nmaxmax; n++) {
+        const int cut = q_max - n;
+        const int H = std::min(std::min(n, LU), cut) + 1, W = std::min(std::min(n, LV), cut) + 1;
+        for (int a = 0; a < H; a++) rowlen[a] = std::max(rowlen[a], std::min(W - 1, cut - a) + 1);
+    }
+    rowoff.assign(LU + 3, 0);
+    rowoff[0] = 0;                 // guard row a = -1: as long as row 0
+    rowoff[1] = rowlen[0] + 1;
+    for (int a = 0; a <= LU; a++) rowoff[a + 2] = rowoff[a + 1] + rowlen[a] + 1;
+    return rowoff[LU + 2];
+}
+
 int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r, hipStream_t st) {
     if (S.geo_valid && S.geo_N == N && S.geo_R == R && S.geo_dr == dr) return 0;
     if (S.geo_valid) HIP_TRY(hipStreamSynchronize(st));  // tables may still be in use by a previous launch
     free_geometry();
     const int nmaxmax = std::min(std::max(last_l, last_r), q_max);
     const int nplanes = nmaxmax + 1;
-    int cap = 0;  // widest in-plane extent the octahedron allows
-    for (int n = 1; n <= nmaxmax; n++) cap = std::max(cap, std::min(n, q_max - n));
+    const int cap = plane_extent(q_max, last_l, last_r);
     const double R2 = R * R, dr2 = dr * dr;
     std::vector<asora::PlaneInfo> planes;
-    std::vector<uint32_t> ab;
-    std::vector<double> pathdr, vol;
+    std::vector<uint2> meta;
+    std::vector<double2> geo;
     std::vector<std::array<int, 3>> keys;  // (LU, LV, order)
+    std::vector<int> rowoff;
+    int entries_max = 0;
     for (int code = 0; code < 8; code++) {
         const int LU = std::min((code & 4) ? last_l : last_r, cap), LV = std::min((code & 2) ? last_l : last_r, cap);
         const int order = code & 1;  // 0: z-sector (U2+V2)+P2, 1: x/y-sector (U2+P2)+V2
@@ -165,15 +192,18 @@ int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
         if (found >= 0) { S.geo_vmap[code] = found; continue; }
         S.geo_vmap[code] = (int)keys.size();
         keys.push_back({LU, LV, order});
+        const int entries = packed_layout(q_max, nmaxmax, LU, LV, rowoff);
+        entries_max = std::max(entries_max, entries);
+        auto pos = [&](int a, int b) { return (uint32_t)(rowoff[a + 1] + b + 1); };
         planes.resize(planes.size() + nplanes);
         asora::PlaneInfo *pl = planes.data() + planes.size() - nplanes;
-        pl[0] = {0, 0, 0, 0};
+        pl[0] = {pos(0, 0), 0, (uint32_t)entries, 0};
         for (int n = 1; n <= nmaxmax; n++) {
             const int cut = q_max - n;
             const int H = std::min(std::min(n, LU), cut) + 1, W = std::min(std::min(n, LV), cut) + 1;
             const double dn = (double)n;
             const double P2 = (dr * dn) * (dr * dn);
-            pl[n].off = (uint32_t)ab.size();
+            pl[n].off = (uint32_t)meta.size();
             pl[n].pad = 0;
             for (int pass = 0; pass < 2; pass++) {
                 for (int a = 0; a < H; a++) {
@@ -186,27 +216,32 @@ int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
                         if (stop != (pass == 1)) continue;
                         const double path = std::sqrt((double)(a * a + b * b) / (dn * dn) + 1.0);
                         const double pd = path * dr;
-                        ab.push_back(((uint32_t)a << 16) | (uint32_t)b);
-                        pathdr.push_back(pd);
-                        vol.push_back(dist2 * pd * asora::FOURPI);
+                        const uint32_t flags = (a == 0 ? asora::FLAG_A0 : 0u) | (b == 0 ? asora::FLAG_B0 : 0u) |
+                                               (a == n ? asora::FLAG_AN : 0u) | (b == n ? asora::FLAG_BN : 0u);
+                        uint2 m;
+                        m.x = (uint32_t)a | ((uint32_t)b << asora::META_COORD_BITS) | (flags << asora::META_FLAG_SHIFT);
+                        m.y = pos(a - 1, b - 1) | (pos(a, b - 1) << 16);
+                        double2 gq;
+                        gq.x = pd;
+                        gq.y = dist2 * pd * asora::FOURPI;
+                        meta.push_back(m);
+                        geo.push_back(gq);
                     }
                 }
-                if (pass == 0) pl[n].cntA = (uint32_t)ab.size() - pl[n].off;
+                if (pass == 0) pl[n].cntA = (uint32_t)meta.size() - pl[n].off;
             }
-            pl[n].cntT = (uint32_t)ab.size() - pl[n].off;
+            pl[n].cntT = (uint32_t)meta.size() - pl[n].off;
         }
     }
-    if (ab.empty()) { ab.push_back(0); pathdr.push_back(0); vol.push_back(0); }
+    if (meta.empty()) { meta.push_back(uint2{0, 0}); geo.push_back(double2{0, 0}); }
     HIP_TRY(hipMalloc(&S.planes_dev, planes.size() * sizeof(asora::PlaneInfo)));
-    HIP_TRY(hipMalloc(&S.cell_ab_dev, ab.size() * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&S.cell_pathdr_dev, pathdr.size() * sizeof(double)));
-    HIP_TRY(hipMalloc(&S.cell_vol_dev, vol.size() * sizeof(double)));
+    HIP_TRY(hipMalloc(&S.cell_meta_dev, meta.size() * sizeof(uint2)));
+    HIP_TRY(hipMalloc(&S.cell_geo_dev, geo.size() * sizeof(double2)));
     // synchronous copies: the host vectors die at the end of this function
     HIP_TRY(hipMemcpy(S.planes_dev, planes.data(), planes.size() * sizeof(asora::PlaneInfo), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(S.cell_ab_dev, ab.data(), ab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(S.cell_pathdr_dev, pathdr.data(), pathdr.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(S.cell_vol_dev, vol.data(), vol.size() * sizeof(double), hipMemcpyHostToDevice));
-    S.geo_N = N; S.geo_R = R; S.geo_dr = dr; S.geo_nplanes = nplanes; S.geo_valid = true;
+    HIP_TRY(hipMemcpy(S.cell_meta_dev, meta.data(), meta.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(S.cell_geo_dev, geo.data(), geo.size() * sizeof(double2), hipMemcpyHostToDevice));
+    S.geo_N = N; S.geo_R = R; S.geo_dr = dr; S.geo_nplanes = nplanes; S.geo_entries = entries_max; S.geo_valid = true;
     return 0;
 }
 
@@ -292,23 +327,34 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     A.R = R; A.sig = sig; A.dr = dr; A.minlogtau = minlogtau; A.dlogtau = dlogtau;
     A.rdlogtau = 1.0 / dlogtau;
     // widest plane any sector stages: max_n min(n, lim, q_max - n) + 1, lim = max(last_l, last_r)
-    int wmax = 0;
-    {
-        const int lim = std::max(A.last_l, A.last_r), nmax = std::min(lim, A.q_max);
-        for (int n = 0; n <= nmax; n++) wmax = std::max(wmax, std::min(std::min(n, lim), A.q_max - n));
-    }
+    const int wmax = plane_extent(A.q_max, A.last_l, A.last_r);
     A.S = wmax + 2;  // b = -1 guard .. wmax
     A.plane_elems = (wmax + 2) * A.S;
-    const size_t lds_tab = asora::LOG10_TABLE_DOUBLES * sizeof(double);  // log10 table, always in LDS
+    A.wtab = wmax + 1;
+    const size_t lds_log = asora::LOG10_TABLE_DOUBLES * sizeof(double);  // log10 table, always in LDS
     const int nmaxmax = std::min(std::max(A.last_l, A.last_r), A.q_max);
-    // the table-driven kernel needs 32-bit cell offsets and 16-bit in-plane coordinates
-    const bool use_tab = !S.force_generic && S.cells < (1ULL << 28) && N < 65536 &&
-                         8 * geometry_cells_per_variant(A.q_max, std::max(A.last_l, A.last_r), nmaxmax) <=
-                             S.max_table_cells;
-    // staged planes: ONE for the table-driven kernel (in-place update), TWO for the table-free one
-    const size_t lds_planes = (use_tab ? 1 : 2) * (size_t)A.plane_elems * sizeof(double);
-    const bool use_lds = lds_planes + lds_tab + (size_t)S.lds_pad <= (size_t)S.max_lds;
-    const size_t lds = (use_lds ? lds_planes : 0) + lds_tab + (size_t)S.lds_pad;
+    // the table-driven kernel needs 32-bit cell offsets, 10-bit in-plane coordinates and 16-bit staging positions
+    bool use_tab = !S.force_generic && S.cells < (1ULL << 28) && wmax < 1024 &&
+                   8 * geometry_cells_per_variant(A.q_max, std::max(A.last_l, A.last_r), nmaxmax) <= S.max_table_cells;
+    if (use_tab && num_src > 0) {
+        if (int rc2 = build_geometry(N, R, dr, A.q_max, A.last_l, A.last_r, st)) return rc2;
+        if (S.geo_entries > 65535) use_tab = false;
+    }
+    size_t lds_stage, lds_fixed;
+    if (use_tab) {
+        // ONE packed array of (column density, weight) pairs, updated in place, + per-row/column tables
+        A.planes = S.planes_dev; A.cell_meta = S.cell_meta_dev; A.cell_geo = S.cell_geo_dev;
+        A.nplanes = S.geo_nplanes; A.cw_entries = S.geo_entries;
+        for (int i = 0; i < 8; i++) A.vmap[i] = S.geo_vmap[i];
+        lds_stage = (size_t)A.cw_entries * 2 * sizeof(double);
+        lds_fixed = (size_t)(5 * A.wtab + (A.wtab & 1) + 2 * A.nplanes) * sizeof(double) + lds_log;
+    } else {
+        lds_stage = 2 * (size_t)A.plane_elems * sizeof(double);  // table-free kernel: two square planes
+        lds_fixed = lds_log;
+    }
+    const bool use_lds = lds_stage + lds_fixed + (size_t)S.lds_pad <= (size_t)S.max_lds;
+    const size_t lds = (use_lds ? lds_stage : 0) + lds_fixed + (size_t)S.lds_pad;
+    if (lds > (size_t)S.max_lds) return fail(13, "asora_do_all_sources: per-row tables (%zu B) exceed LDS", lds);
 
     S.timed = false;
     int grid, rc = 0;
@@ -317,7 +363,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             grid = (int)std::min<long long>(A.ntasks, 0x7fffffffLL);
         } else {
             grid = (int)std::min<long long>(A.ntasks, (long long)S.num_cu * 4);
-            const size_t need = (size_t)grid * lds_planes;
+            const size_t need = (size_t)grid * lds_stage;
             if (need > S.gscratch_bytes) {
                 if (S.gscratch) (void)hipFree(S.gscratch);
                 S.gscratch = nullptr;
@@ -326,12 +372,6 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
                 S.gscratch_bytes = need;
             }
             A.gscratch = S.gscratch;
-        }
-        if (use_tab) {
-            if (int rc2 = build_geometry(N, R, dr, A.q_max, A.last_l, A.last_r, st)) return rc2;
-            A.planes = S.planes_dev; A.cell_ab = S.cell_ab_dev; A.cell_pathdr = S.cell_pathdr_dev;
-            A.cell_vol = S.cell_vol_dev; A.nplanes = S.geo_nplanes;
-            for (int i = 0; i < 8; i++) A.vmap[i] = S.geo_vmap[i];
         }
         S.last_tab = use_tab ? 1 : 0;
         HIP_TRY(hipEventRecord(S.ev0, st));

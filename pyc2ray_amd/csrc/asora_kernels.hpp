@@ -55,6 +55,7 @@ constexpr double SQRT2_CUDA = 1.41421356237;
 
 // One plane of one geometry variant in the cell tables: cells [off, off+cntA) produce rates
 // (dist2/dr2 <= R2 with the oracle's exact arithmetic), [off+cntA, off+cntT) only propagate cdh.
+// Entry 0 of a variant (the source plane) holds off = staging position of cell (0, 0).
 struct PlaneInfo {
     uint32_t off, cntA, cntT, pad;
 };
@@ -81,10 +82,12 @@ struct SweepArgs {
     double rdlogtau;        // correctly rounded 1/dlogtau (host)
     // table-driven fast path (sweep_tab_kernel)
     const PlaneInfo *planes;   // [variant][nplanes]
-    const uint32_t *cell_ab;   // (a << 16) | b, list A (rate-producing) then list B per plane
-    const double *cell_pathdr; // path * dr
-    const double *cell_vol;    // vol_ph = dist2 * (path*dr) * 4pi
+    const uint2 *cell_meta;    // .x = a | b << 10 | flags << 20, .y = staging position of (a-1,b-1) | of (a,b-1) << 16;
+                               // list A (rate-producing) then list B per plane
+    const double2 *cell_geo;   // {path * dr, vol_ph = dist2 * (path*dr) * 4pi}
     int nplanes;
+    int cw_entries;            // staged (column density, weight) pairs per task (max over variants)
+    int wtab;                  // rows/columns per plane (max) = entries of the per-row / per-column LDS tables
     int vmap[8];               // ((u_is_neg*2 + v_is_neg)*2 + (axis != 0)) -> variant
 };
 
@@ -125,7 +128,7 @@ struct Lookup {
 };
 
 // log10 through the LDS-resident table of asora_log10.hpp (ASORA_OCML_LOG10: device library's log10)
-extern __shared__ double asora_smem[];
+extern __shared__ __attribute__((aligned(16))) double asora_smem[];
 struct Log10LDS {
     int off;  // position of the log10 table in dynamic LDS (doubles)
     __device__ __forceinline__ double operator()(double x) const {
@@ -182,6 +185,69 @@ __device__ __forceinline__ void cell_rates(const SweepArgs &A, Log10LDS lg, doub
     }
     phi = div_exact(phi, nHI);
     if (HEAT) heat = div_exact(heat, nHI);
+}
+
+// The same rates in three steps, so that a wave can have the table look-ups of several cells in
+// flight at once: (1) optical depths and table positions, (2) the loads, (3) the arithmetic.  Both
+// branches of photorates.f90:113-125 are evaluated and the result is selected, which is
+// bit-identical to taking the branch.
+struct RatePrep {
+    Lookup Lin, Lout;
+    double prefact, dtau;
+};
+struct RateLoads {
+    double2 thick_in, thick_out, hthick_in, hthick_out;
+};
+__device__ __forceinline__ RatePrep rates_prepare(const SweepArgs &A, Log10LDS lg, double flux, double cdh_in,
+                                                  double cdh_out, double vol_ph) {
+    RatePrep r;
+    const double tau_in = cdh_in * A.sig;
+    const double tau_out = cdh_out * A.sig;
+    r.prefact = div_exact(flux, vol_ph);
+    r.dtau = tau_out - tau_in;
+    r.Lin = table_index(tau_in, A.minlogtau, A.dlogtau, A.rdlogtau, A.num_tau, lg);
+    r.Lout = table_index(tau_out, A.minlogtau, A.dlogtau, A.rdlogtau, A.num_tau, lg);
+    return r;
+}
+__device__ __forceinline__ double2 table_pair(const double *__restrict__ t, int i0) {
+    double2 v;
+    v.x = t[i0];
+    v.y = t[i0 + 1];
+    return v;
+}
+template <bool HEAT>
+__device__ __forceinline__ RateLoads rates_load(const SweepArgs &A, const RatePrep &r) {
+    RateLoads l;
+    l.thick_in = table_pair(A.thick, r.Lin.i0);
+    l.thick_out = table_pair(A.thick, r.Lout.i0);
+    if (HEAT) {
+        l.hthick_in = table_pair(A.hthick, r.Lin.i0);
+        l.hthick_out = table_pair(A.hthick, r.Lout.i0);
+    }
+    return l;
+}
+__device__ __forceinline__ double pair_eval(double2 t, double residual) { return t.x + residual * (t.y - t.x); }
+template <bool HEAT>
+__device__ __forceinline__ void rates_finish(const SweepArgs &A, const RatePrep &r, const RateLoads &l, double nHI,
+                                             double &phi, double &heat) {
+    const double tau_photo_limit = (double)1.0e-7f;
+    const bool thick = fabs(r.dtau) > tau_photo_limit;
+    const double phi_in = r.prefact * pair_eval(l.thick_in, r.Lin.residual);
+    const double phi_out = r.prefact * pair_eval(l.thick_out, r.Lout.residual);
+    double p = phi_in - phi_out;
+    double h = 0.0;
+    if (HEAT) h = r.prefact * (pair_eval(l.hthick_in, r.Lin.residual) - pair_eval(l.hthick_out, r.Lout.residual));
+    // optically thin cells are rare: their table is only touched by waves that hold one
+    if (__builtin_amdgcn_ballot_w64(!thick) != 0) {
+        const double p_thin = r.prefact * r.dtau * pair_eval(table_pair(A.thin, r.Lin.i0), r.Lin.residual);
+        p = thick ? p : p_thin;
+        if (HEAT) {
+            const double h_thin = r.prefact * r.dtau * pair_eval(table_pair(A.hthin, r.Lin.i0), r.Lin.residual);
+            h = thick ? h : h_thin;
+        }
+    }
+    phi = div_exact(p, nHI);
+    if (HEAT) heat = div_exact(h, nHI);
 }
 
 // raytracing.f90:807-813
@@ -374,140 +440,183 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
 
 // ------------------------------------------------------------------------------------------
 // Table-driven sweep (the fast path).  Same task decomposition and arithmetic as sweep_kernel;
-// everything about a cell that depends only on its offset (n, a, b) from the source -- membership
-// in the octahedron/box, the oracle's exact R-sphere predicate, path*dr and vol_ph -- is computed
-// once per call on the host with the same IEEE operations (build_geometry in asora_capi.hip) and
-// streamed from L2.  Per plane the cells come as two dense lists: A (inside the R sphere: column
-// density + rates) and B (outside: column density only), cut into 64-cell chunks, so wavefronts
-// are fully populated and never diverge on the sphere or the octahedron cut.
+// the kernel is bound by VALU issue (rocprofv3: 62 % VALU busy, 244 instructions per wave-visit in
+// the first version), so everything that is not the oracle's f64 arithmetic on cell DATA is
+// moved out of the per-cell path:
 //
-// ONE plane of column densities is staged (in LDS), updated IN PLACE: occupancy on this kernel is
-// worth more than anything else (measured: 3 -> 2 workgroups per CU costs 29 %), and a single
-// plane halves the LDS footprint.  In-place is safe because of the processing order.  A plane is
-// worked off in PHASES of up to NW*P chunks; within a phase every wave first computes its cells
-// from the old values (results stay in registers), then -- after a barrier -- all waves write.
-// Across phases chunks are taken in DECREASING order: list B from its last chunk down, then list A
-// from its last chunk down.  Cell (a, b) reads the old values at (a-1,b-1), (a,b-1), (a-1,b), (a,b):
-// all at row-major positions <= its own, and for an A cell all inside list A (the sphere's row
-// extent shrinks with a), so nothing it reads has been overwritten by an earlier phase.
-// Positions a plane does not write (beyond the octahedron cut) are never read later with
-// non-zero weight; never-written positions and the guard row/column read as 0.
+//   * per (N, R, dr), on the host (build_geometry in asora_capi.hip), with the same IEEE operations
+//     as the oracle: membership in octahedron ∩ box, the exact R-sphere predicate, path*dr, vol_ph,
+//     the ownership flags and the staging positions of every cell -> 24 B per cell, streamed from
+//     L2 / Infinity Cache.  Per plane the cells form two dense lists: A (inside the R sphere:
+//     column density + rates) and B (outside: column density only), cut into 64-cell chunks, so
+//     wavefronts are fully populated and never diverge on the sphere or the octahedron cut.
+//   * per task, by the workgroup, into LDS: the periodic wrap of every row and column
+//     (rowU[a], colV[b]: a cell's grid offset is base + rowU[a] + colV[b]).
+//   * per plane, by the workgroup, into LDS: the interpolation offsets, which depend only on the row
+//     (du[a], 1 - du[a]) or only on the column (dv[b], 1 - dv[b]) -- raytracing.f90:688-700.
+//   * per PRODUCED cell instead of per consumed cell: the weight 1/max(0.6, tau) (raytracing.f90:
+//     807-813) is stored next to the column density; each staged value is read by four cells.
+//
+// Staging.  ONE array of (column density, weight) pairs, in LDS, updated IN PLACE, laid out as the
+// packed union of all planes' domains (rows of decreasing length, one leading guard per row and
+// a guard row): 16 B x ~2000 entries at R = 60.  Occupancy on this kernel is worth a lot (measured:
+// 3 -> 2 workgroups per CU costs 29 %), hence the packing and the single array.  In-place is safe
+// because of the processing order.  A plane is worked off in PHASES of up to NW*P chunks; within a
+// phase every wave first computes its cells from the old values (results stay in registers),
+// then -- after a barrier -- all waves write.  Across phases chunks are taken in DECREASING order:
+// list B from its last chunk down, then list A from its last chunk down.  Cell (a, b) reads the old
+// values at (a-1,b-1), (a,b-1), (a-1,b), (a,b): all at row-major positions <= its own, and for an
+// A cell all inside list A (the sphere's row extent shrinks with a), so nothing it reads has been
+// overwritten by an earlier phase.  Positions a plane does not write (beyond the octahedron cut)
+// are never read later with non-zero weight; never-written positions and guards hold (0, 1/0.6).
 // ------------------------------------------------------------------------------------------
 #ifndef ASORA_GROUP
 #define ASORA_GROUP 1
 #endif
+// chunks per wave per phase: 1 keeps the kernel at 117 VGPRs (4 waves/SIMD without spills); measured best
 #ifndef ASORA_PHASE_CHUNKS
-#define ASORA_PHASE_CHUNKS 4
+#define ASORA_PHASE_CHUNKS 1
 #endif
+#ifndef ASORA_WAVES_PER_EU
+#define ASORA_WAVES_PER_EU 4
+#endif
+
+// cell_meta.x
+constexpr uint32_t META_COORD_BITS = 10, META_COORD_MASK = (1u << META_COORD_BITS) - 1;
+constexpr uint32_t META_FLAG_SHIFT = 2 * META_COORD_BITS;
+enum : uint32_t { FLAG_A0 = 1, FLAG_B0 = 2, FLAG_AN = 4, FLAG_BN = 8 };  // a == 0, b == 0, a == n, b == n
+
+template <bool LDS_STAGE>
+struct StageCW {
+    double2 *g;  // global staging (when LDS is too small)
+    __device__ __forceinline__ double2 ld(uint32_t p) const {
+        if (LDS_STAGE) return reinterpret_cast<const double2 *>(asora_smem)[p];
+        return g[p];
+    }
+    __device__ __forceinline__ void st(uint32_t p, double c, double w) const {
+        double2 v;
+        v.x = c;
+        v.y = w;
+        if (LDS_STAGE) reinterpret_cast<double2 *>(asora_smem)[p] = v;
+        else g[p] = v;
+    }
+};
 
 // Everything the cells of one plane of one task share.
 template <bool LDS_STAGE>
 struct PlaneCtx {
-    Stage<LDS_STAGE> stg;
+    StageCW<LDS_STAGE> stg;
     Log10LDS lg;
     const double *__restrict__ nhi;
     double *__restrict__ phi;
     double *__restrict__ heat;
     double *__restrict__ cdh;  // null unless this task exports its column density
-    const uint32_t *__restrict__ cab;  // tables of the current plane
-    const double *__restrict__ cpd;
-    const double *__restrict__ cvol;
-    uint32_t baseP, strideU;
-    double alam, flux;
-    int n, S, N, u0, v0, su, sv, axis;
-    int cntA, cntT, nchunkA, nchunkB;
+    const uint2 *__restrict__ meta;  // tables of the current plane
+    const double2 *__restrict__ geo;
+    const double2 *du, *dv;          // LDS: {d, 1 - d} per row / per column of the current plane
+    const int *rowU, *colV;          // LDS: wrapped grid offsets per row / per column
+    uint32_t baseP, ghostmask;
+    double flux;
+    int n, cntA, cntT, nchunkA, nchunkB;
 };
 
-// G chunks of one wave (sequence positions j, j + NW, ...): all table loads, then all nHI loads and
-// LDS reads, then the arithmetic.  Three dependent memory round trips per GROUP instead of per
-// cell.  Results (new column density + LDS position) are returned for the deferred write.
-template <int G, bool HEAT, bool LDS_STAGE>
-__device__ __forceinline__ void process_group(const SweepArgs &A, const PlaneCtx<LDS_STAGE> &C, int j, int lane,
-                                              double *cdo_out, int *woff_out) {
-    constexpr int NW = SWEEP_THREADS / 64;
-    const double max_coldensh = (double)2e30f;  // raytracing.f90:368
-    const int nchunk = C.nchunkA + C.nchunkB;
-    bool valid[G], isA[G];
-    uint32_t idx[G], ab[G], g[G];
-    double pathdr[G], vol[G], nHI[G], c1[G], c2[G], c3[G], c4[G];
-#pragma unroll
-    for (int k = 0; k < G; k++) {
-        const int jj = j + k * NW;  // wave-uniform
-        // decreasing order: B chunks from the last down, then A chunks from the last down
-        isA[k] = jj >= C.nchunkB;
-        const int c = isA[k] ? C.nchunkA - 1 - (jj - C.nchunkB) : C.nchunkB - 1 - jj;
-        const int i = isA[k] ? c * 64 + lane : C.cntA + c * 64 + lane;
-        const int lim = isA[k] ? C.cntA : C.cntT;
-        valid[k] = (jj < nchunk) && (i < lim);
-        idx[k] = (uint32_t)(valid[k] ? i : 0);
-        ab[k] = C.cab[idx[k]];
-        pathdr[k] = C.cpd[idx[k]];
-        vol[k] = C.cvol[idx[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < G; k++) {
-        const int a = (int)(ab[k] >> 16), b = (int)(ab[k] & 0xffffu);
-        const int uw = wrap(C.u0 + C.su * a, C.N), vw = wrap(C.v0 + C.sv * b, C.N);
-        g[k] = C.baseP + (uint32_t)uw * C.strideU + (uint32_t)vw;
-        nHI[k] = C.nhi[g[k]];
-        const int o = a * C.S + b;
-        c1[k] = C.stg.ld(o);
-        c3[k] = C.stg.ld(o + 1);
-        c2[k] = C.stg.ld(o + C.S);
-        c4[k] = C.stg.ld(o + C.S + 1);
-    }
-#pragma unroll
-    for (int k = 0; k < G; k++) {
-        const int a = (int)(ab[k] >> 16), b = (int)(ab[k] & 0xffffu);
-        const double cdh_in = cinterp_cd(C.n, a, b, C.su, C.sv, C.u0 + 1, C.v0 + 1, C.alam, c1[k], c2[k], c3[k], c4[k],
-                                         A.sig, SQRT3_F32, SQRT2_F32);
-        const double cdo = cdh_in + nHI[k] * pathdr[k];
-        // ownership: reference tie order (z, y, x) and sign(0) = +1
-        const bool ghost = (C.su < 0 && a == 0) || (C.sv < 0 && b == 0) || (C.axis >= 1 && b == C.n) ||
-                           (C.axis == 2 && a == C.n);
-        cdo_out[k] = cdo;
-        woff_out[k] = valid[k] ? (a + 1) * C.S + b + 1 : -1;
-        if (valid[k] && !ghost) {
-            if (C.cdh) C.cdh[g[k]] = cdo;
-            if (isA[k]) {
-#ifdef ASORA_ABL_NORATES
-                if (cdh_in == 1.2345e300) {  // ablation build: column densities only
-#else
-                if (!(cdh_in > max_coldensh)) {
-#endif
-                    double ph, ht = 0.0;
-                    cell_rates<HEAT>(A, C.lg, C.flux, cdh_in, cdo, vol[k], nHI[k], ph, ht);
-#ifdef ASORA_ABL_NOATOMIC
-                    if (ph == 1.2345e300)  // ablation build: rates computed, (almost) never added
-#endif
-                    unsafeAtomicAdd(C.phi + g[k], ph);
-                    if (HEAT) unsafeAtomicAdd(C.heat + g[k], ht);
-                }
-            }
-        }
-    }
+// raytracing.f90:683-700 for one row (or column): x1 = 1-based source coordinate, s = sign
+__device__ __forceinline__ double2 interp_offsets(int i, int s, int x1, double alam) {
+    const double dX = (double)(s * i);
+    const double xc = alam * dX + (double)x1;
+    const double xh = (double)(x1 + s * (i - 1)) + 0.5 * (double)s;
+    double2 r;
+    r.x = 2.0 * fabs(xc - xh);
+    r.y = 1. - r.x;
+    return r;
 }
 
-// register budget: 5 waves per SIMD (<= 96 VGPRs; measured faster than 4 or 6 on the 256^3 / R = 60 sweep)
-#ifndef ASORA_WAVES_PER_EU
-#define ASORA_WAVES_PER_EU 5
+// One PHASE of one plane: the chunks [jbase, jbase + NW*P) of the plane's decreasing chunk sequence.
+// Everything here is wave-uniform (SGPRs).
+struct PhaseDesc {
+    int n, jbase;
+    uint32_t off;
+    int cntA, cntT, nchunkA, nchunkB;
+    bool valid;
+};
+__device__ __forceinline__ void phase_load_plane(PhaseDesc &d, const PlaneInfo *planes, int nmax) {
+    d.valid = d.n <= nmax;
+    if (d.valid) {
+        const PlaneInfo pi = planes[d.n];
+        d.off = pi.off;
+        d.cntA = (int)pi.cntA;
+        d.cntT = (int)pi.cntT;
+        d.nchunkA = (d.cntA + 63) >> 6;
+        d.nchunkB = (d.cntT - d.cntA + 63) >> 6;
+    }
+}
+template <int STEP>
+__device__ __forceinline__ PhaseDesc phase_next(PhaseDesc d, const PlaneInfo *planes, int nmax) {
+    if (!d.valid) return d;
+    d.jbase += STEP;
+    if (d.jbase >= d.nchunkA + d.nchunkB) {
+        d.n++;
+        d.jbase = 0;
+        phase_load_plane(d, planes, nmax);
+    }
+    return d;
+}
+// slot q of this wave in phase d: table index of the lane's cell (0 when the lane has none)
+template <int NW>
+__device__ __forceinline__ uint32_t slot_index(const PhaseDesc &d, int wave, int q, int lane, bool &valid, bool &isA) {
+    const int jj = d.jbase + wave + q * NW;  // wave-uniform
+    // decreasing order: B chunks from the last down, then A chunks from the last down
+    isA = jj >= d.nchunkB;
+    const int c = isA ? d.nchunkA - 1 - (jj - d.nchunkB) : d.nchunkB - 1 - jj;
+    const int i = isA ? c * 64 + lane : d.cntA + c * 64 + lane;
+    const int lim = isA ? d.cntA : d.cntT;
+    valid = d.valid && (jj < d.nchunkA + d.nchunkB) && (i < lim);
+    return (uint32_t)(valid ? i : 0);
+}
+
+// The sweep is latency-bound (rocprofv3: waves wait 73 % of their cycles; an ablation without the
+// f64 atomics runs 30 % faster, without barriers only 5 %), so the memory operations of a phase are
+// issued one to two phases ahead, in plain C++ (the compiler keeps the s_waitcnt bookkeeping):
+//     top of phase p : geometry + neutral density of phase p+1 (their addresses need the cell
+//                      coordinates of p+1, loaded during phase p-1), cell coordinates of phase p+2
+//     phase p        : staging reads, interpolation, rates; the rates' table look-ups are the only
+//                      point where the wave drains its memory counter, and everything in flight
+//                      there was issued at least one interpolation pass earlier
+//     end of phase p : all f64 atomics of the phase in one burst (they complete behind the
+//                      barriers and the next phase's interpolation), barrier, deferred staging
+//                      writes, barrier.  The barriers wait for LDS traffic only.
+template <bool LDS_STAGE>
+__device__ __forceinline__ void phase_barrier() {
+#if defined(ASORA_ABL_NOBARRIER)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ablation build: WRONG results
+#else
+    if (LDS_STAGE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();  // staging in global memory: stores must have completed
 #endif
+}
+
 template <bool LDS_STAGE, bool HEAT>
 __global__ __launch_bounds__(SWEEP_THREADS) __attribute__((amdgpu_waves_per_eu(ASORA_WAVES_PER_EU, ASORA_WAVES_PER_EU)))
 void sweep_tab_kernel(SweepArgs A) {
-    constexpr int G = ASORA_GROUP, P = ASORA_PHASE_CHUNKS, NW = SWEEP_THREADS / 64;
-    static_assert(P % G == 0, "a phase is a whole number of groups");
+    constexpr int P = ASORA_PHASE_CHUNKS, NW = SWEEP_THREADS / 64;
+    const double max_coldensh = (double)2e30f;  // raytracing.f90:368
     PlaneCtx<LDS_STAGE> C;
-    C.stg.g = LDS_STAGE ? nullptr : A.gscratch + (size_t)blockIdx.x * (size_t)A.plane_elems;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int S = A.S;
-    const int plane = A.plane_elems;
     const int N = A.N;
     const uint32_t N2 = (uint32_t)N * (uint32_t)N;
-    C.lg = load_log10_table(A.log10_table, LDS_STAGE ? plane : 0, tid, SWEEP_THREADS);
-    C.S = S;
-    C.N = N;
+    // LDS (in doubles): [cw pairs: 2*E (LDS staging only)] [du: 2W] [dv: 2W] [rowU, colV: W ints each] [log10 table]
+    const int E = A.cw_entries, W = A.wtab;
+    const int off_du = LDS_STAGE ? 2 * E : 0;
+    double2 *const du_tab = reinterpret_cast<double2 *>(asora_smem + off_du);
+    double2 *const dv_tab = du_tab + W;
+    int *const rowU = reinterpret_cast<int *>(asora_smem + off_du + 4 * W);
+    int *const colV = rowU + W;
+    // the variant's plane table: read through LDS so that stepping to the next plane never touches vmcnt
+    PlaneInfo *const planes = reinterpret_cast<PlaneInfo *>(asora_smem + off_du + 5 * W + (W & 1));
+    C.stg.g = LDS_STAGE ? nullptr : reinterpret_cast<double2 *>(A.gscratch) + (size_t)blockIdx.x * (size_t)E;
+    C.lg = load_log10_table(A.log10_table, off_du + 5 * W + (W & 1) + 2 * A.nplanes, tid, SWEEP_THREADS);
+    const double w_empty = weightf(0.0, A.sig);  // weight of a guard / never-written entry
 
     for (long long task = blockIdx.x; task < A.ntasks; task += gridDim.x) {
         const int s = (int)(task / SECTORS);
@@ -522,70 +631,218 @@ void sweep_tab_kernel(SweepArgs A) {
         if (axis == 0) { p0 = k0; u0 = i0; v0 = j0; }
         else if (axis == 1) { p0 = j0; u0 = i0; v0 = k0; }
         else { p0 = i0; u0 = j0; v0 = k0; }
-        C.flux = A.src_flux[src];
-        C.nhi = (axis == 0) ? A.nhiB : A.nhiA;
-        C.phi = (axis == 0) ? A.phiB : A.phiA;
-        C.heat = (axis == 0) ? A.heatB : A.heatA;
-        C.cdh = (src == A.cdh_src) ? ((axis == 0) ? A.cdhB : A.cdhA) : nullptr;
-        C.u0 = u0; C.v0 = v0; C.su = su; C.sv = sv; C.axis = axis;
+        const double flux = A.src_flux[src];
+        const double *__restrict__ nhi = (axis == 0) ? A.nhiB : A.nhiA;
+        double *__restrict__ phi = (axis == 0) ? A.phiB : A.phiA;
+        double *__restrict__ heat = (axis == 0) ? A.heatB : A.heatA;
+        double *__restrict__ cdh = (src == A.cdh_src) ? ((axis == 0) ? A.cdhB : A.cdhA) : nullptr;
+        // ownership: reference tie order (z, y, x) and sign(0) = +1
+        const uint32_t ghostmask = (su < 0 ? FLAG_A0 : 0u) | (sv < 0 ? FLAG_B0 : 0u) | (axis >= 1 ? FLAG_BN : 0u) |
+                                   (axis == 2 ? FLAG_AN : 0u);
         const int nmax = min(sp > 0 ? A.last_r : A.last_l, A.q_max);
         const uint32_t strideP = (axis == 2) ? N2 : (uint32_t)N;
-        C.strideU = (axis == 2) ? (uint32_t)N : N2;
+        const uint32_t strideU = (axis == 2) ? (uint32_t)N : N2;
         const int variant = A.vmap[(((su < 0) ? 2 : 0) + ((sv < 0) ? 1 : 0)) * 2 + (axis != 0 ? 1 : 0)];
-        const PlaneInfo *__restrict__ planes = A.planes + (size_t)variant * A.nplanes;
+        // (the previous task's last barrier guarantees nobody still reads the plane table)
+        for (int i = tid; i < A.nplanes; i += SWEEP_THREADS) planes[i] = A.planes[(size_t)variant * A.nplanes + i];
+        __syncthreads();
+        const uint32_t pos00 = planes[0].off;  // staging position of cell (0, 0) in this variant's layout
 
-        // guard cells and never-written cells must read as 0 (their weights are 0 or O(eps))
-        for (int i = tid; i < plane; i += SWEEP_THREADS) C.stg.st(i, 0.0);
+        // phase descriptors of p, p+1, p+2 and the cell coordinates of p and p+1
+        PhaseDesc d0, d1, d2;
+        d0.n = 1; d0.jbase = 0; d0.off = 0; d0.cntA = d0.cntT = d0.nchunkA = d0.nchunkB = 0;
+        phase_load_plane(d0, planes, nmax);
+        d1 = phase_next<NW * P>(d0, planes, nmax);
+        uint2 meta_c[P], meta_n[P];
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            bool v, ia;
+            meta_c[q] = A.cell_meta[d0.off + slot_index<NW>(d0, wave, q, lane, v, ia)];
+            meta_n[q] = A.cell_meta[d1.off + slot_index<NW>(d1, wave, q, lane, v, ia)];
+        }
+
+        // (the previous task's last barrier guarantees nobody still reads the arrays below)
+        for (int i = tid; i < E; i += SWEEP_THREADS) C.stg.st((uint32_t)i, 0.0, w_empty);
+        for (int i = tid; i < W; i += SWEEP_THREADS) {
+            rowU[i] = (int)((uint32_t)wrap(u0 + su * i, N) * strideU);
+            colV[i] = wrap(v0 + sv * i, N);
+        }
+        {
+            const double alam = cinterp_alam(1);
+            for (int i = tid; i < 2 * W; i += SWEEP_THREADS) {
+                if (i < W) du_tab[i] = interp_offsets(i, su, u0 + 1, alam);
+                else dv_tab[i - W] = interp_offsets(i - W, sv, v0 + 1, alam);
+            }
+        }
         __syncthreads();
         if (tid == 0) {
             // source cell, raytracing.f90:430-439
-            const uint32_t g0 = (uint32_t)p0 * strideP + (uint32_t)u0 * C.strideU + (uint32_t)v0;
-            double nHI = C.nhi[g0];
+            const uint32_t g0 = (uint32_t)p0 * strideP + (uint32_t)u0 * strideU + (uint32_t)v0;
+            double nHI = nhi[g0];
             double path = 0.5 * A.dr;
             double cdo = 0.0 + nHI * path;
-            C.stg.st(S + 1, cdo);
+            C.stg.st(pos00, cdo, weightf(cdo, A.sig));
             if (t == 0) {
                 double vol_ph = A.dr * A.dr * A.dr;
                 double ph, ht = 0.0;
-                cell_rates<HEAT>(A, C.lg, C.flux, 0.0, cdo, vol_ph, nHI, ph, ht);
-                unsafeAtomicAdd(C.phi + g0, ph);
-                if (HEAT) unsafeAtomicAdd(C.heat + g0, ht);
-                if (C.cdh) C.cdh[g0] = cdo;
+                cell_rates<HEAT>(A, C.lg, flux, 0.0, cdo, vol_ph, nHI, ph, ht);
+                unsafeAtomicAdd(phi + g0, ph);
+                if (HEAT) unsafeAtomicAdd(heat + g0, ht);
+                if (cdh) cdh[g0] = cdo;
             }
         }
         __syncthreads();
 
-        for (int n = 1; n <= nmax; n++) {
-            const PlaneInfo pi = planes[n];
-            C.n = n;
-            C.alam = cinterp_alam(n);
-            C.baseP = (uint32_t)wrap(p0 + sp * n, N) * strideP;
-            C.cab = A.cell_ab + pi.off;
-            C.cpd = A.cell_pathdr + pi.off;
-            C.cvol = A.cell_vol + pi.off;
-            C.cntA = (int)pi.cntA;
-            C.cntT = (int)pi.cntT;
-            C.nchunkA = (C.cntA + 63) >> 6;
-            C.nchunkB = (C.cntT - C.cntA + 63) >> 6;
-            const int nchunk = C.nchunkA + C.nchunkB;
-            for (int jbase = 0; jbase < nchunk; jbase += NW * P) {
-                double cdo[P];
-                int woff[P];
+        // geometry + neutral density of the first phase (rowU / colV are ready now)
+        double2 geo_c[P], geo_n[P];
+        double nhi_c[P], nhi_n[P];
+        uint32_t g_c[P], g_n[P];
+        {
+            const uint32_t baseP = (uint32_t)wrap(p0 + sp * d0.n, N) * strideP;
 #pragma unroll
-                for (int q = 0; q < P; q += G) {
-                    const int j = jbase + wave + q * NW;
-                    if (j < nchunk) {
-                        process_group<G, HEAT, LDS_STAGE>(A, C, j, lane, cdo + q, woff + q);
-                    } else {
+            for (int q = 0; q < P; q++) {
+                bool v, ia;
+                const uint32_t idx = slot_index<NW>(d0, wave, q, lane, v, ia);
+                const uint32_t a = meta_c[q].x & META_COORD_MASK, b = (meta_c[q].x >> META_COORD_BITS) & META_COORD_MASK;
+                g_c[q] = baseP + (uint32_t)rowU[a] + (uint32_t)colV[b];
+                geo_c[q] = A.cell_geo[d0.off + idx];
+                nhi_c[q] = nhi[g_c[q]];
+            }
+        }
+
+        while (d0.valid) {
+            // ---- issue the loads of the coming phases -------------------------------------------
+            d2 = phase_next<NW * P>(d1, planes, nmax);
+            uint2 meta_nn[P];
+            if (d1.valid) {
+                const uint32_t baseP = (uint32_t)wrap(p0 + sp * d1.n, N) * strideP;
 #pragma unroll
-                        for (int k = 0; k < G; k++) { cdo[q + k] = 0.0; woff[q + k] = -1; }
-                    }
+                for (int q = 0; q < P; q++) {
+                    bool v, ia;
+                    const uint32_t idx = slot_index<NW>(d1, wave, q, lane, v, ia);
+                    const uint32_t a = meta_n[q].x & META_COORD_MASK, b = (meta_n[q].x >> META_COORD_BITS) & META_COORD_MASK;
+                    g_n[q] = baseP + (uint32_t)rowU[a] + (uint32_t)colV[b];
+                    geo_n[q] = A.cell_geo[d1.off + idx];
+                    nhi_n[q] = nhi[g_n[q]];
                 }
-                __syncthreads();  // every wave has read the old values it needs
+            }
+            if (d2.valid) {
 #pragma unroll
-                for (int q = 0; q < P; q++)
-                    if (woff[q] >= 0) C.stg.st(woff[q], cdo[q]);
-                __syncthreads();  // new values visible
+                for (int q = 0; q < P; q++) {
+                    bool v, ia;
+                    meta_nn[q] = A.cell_meta[d2.off + slot_index<NW>(d2, wave, q, lane, v, ia)];
+                }
+            }
+
+            // ---- phase p: interpolation and rates from the old staged values ---------------------
+            // in stages over the P slots, so that the slots' dependency chains interleave and all
+            // table look-ups of the phase are in flight together
+            const int n = d0.n;
+            double cdo[P], wo[P], ph[P], ht[HEAT ? P : 1], cin[P];
+            int woff[P];
+            bool fire[P], rate_slot[P];
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+                bool valid, isA;
+                (void)slot_index<NW>(d0, wave, q, lane, valid, isA);
+                const bool slot_on = d0.jbase + wave + q * NW < d0.nchunkA + d0.nchunkB;  // wave-uniform
+                fire[q] = false;
+                rate_slot[q] = slot_on && isA;
+                ph[q] = 0.0;
+                if (HEAT) ht[q] = 0.0;
+                woff[q] = -1;
+                cdo[q] = 0.0;
+                wo[q] = 0.0;
+                cin[q] = 0.0;
+                if (slot_on) {
+                    const uint2 m = meta_c[q];
+                    const uint32_t a = m.x & META_COORD_MASK, b = (m.x >> META_COORD_BITS) & META_COORD_MASK;
+                    const double2 du = du_tab[a], dv = dv_tab[b];
+                    const uint32_t o_up = m.y & 0xffffu, o_cur = m.y >> 16;
+                    const double2 e1 = C.stg.ld(o_up);       // (a-1, b-1)
+                    const double2 e3 = C.stg.ld(o_up + 1);   // (a-1, b)
+                    const double2 e2 = C.stg.ld(o_cur);      // (a,   b-1)
+                    const double2 e4 = C.stg.ld(o_cur + 1);  // (a,   b)
+                    // raytracing.f90:701-709 (weights read instead of recomputed)
+                    const double s1 = du.y * dv.y;
+                    const double s2 = dv.y * du.x;
+                    const double s3 = du.y * dv.x;
+                    const double s4 = du.x * dv.x;
+                    const double w1 = s1 * e1.y;
+                    const double w2 = s2 * e2.y;
+                    const double w3 = s3 * e3.y;
+                    const double w4 = s4 * e4.y;
+                    double cdh_in = div_exact(e1.x * w1 + e2.x * w2 + e3.x * w3 + e4.x * w4, w1 + w2 + w3 + w4);
+                    if (n == 1) {  // the 20 diagonal nearest neighbours, raytracing.f90:703-708
+                        if (a == 1 && b == 1) cdh_in = SQRT3_F32 * cdh_in;
+                        else if (a == 1 || b == 1) cdh_in = SQRT2_F32 * cdh_in;
+                    }
+                    const double c_out = cdh_in + nhi_c[q] * geo_c[q].x;
+                    cin[q] = cdh_in;
+                    cdo[q] = c_out;
+                    wo[q] = weightf(c_out, A.sig);
+                    woff[q] = valid ? (int)o_cur + 1 : -1;
+                    const bool ghost = ((m.x >> META_FLAG_SHIFT) & ghostmask) != 0;
+                    const bool own = valid && !ghost;
+                    if (cdh && own) cdh[g_c[q]] = c_out;
+#ifdef ASORA_ABL_NORATES
+                    fire[q] = own && isA && cdh_in == 1.2345e300;  // ablation build: column densities only
+                    rate_slot[q] = false;
+#else
+                    fire[q] = own && isA && !(cdh_in > max_coldensh);
+#endif
+                }
+            }
+            RatePrep rp[P];
+            RateLoads rl[P];
+#pragma unroll
+            for (int q = 0; q < P; q++)
+                if (rate_slot[q]) rp[q] = rates_prepare(A, C.lg, flux, cin[q], cdo[q], geo_c[q].y);
+#pragma unroll
+            for (int q = 0; q < P; q++)
+                if (rate_slot[q]) rl[q] = rates_load<HEAT>(A, rp[q]);
+#pragma unroll
+            for (int q = 0; q < P; q++)
+                if (rate_slot[q]) {
+                    double p_, h_ = 0.0;
+                    rates_finish<HEAT>(A, rp[q], rl[q], nhi_c[q], p_, h_);
+                    ph[q] = p_;
+                    if (HEAT) ht[q] = h_;
+                }
+            // ---- all atomics of the phase, after its last table look-up --------------------------
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+#ifdef ASORA_ABL_NOATOMIC
+                if (fire[q] && ph[q] == 1.2345e300) {  // ablation build: rates computed, (almost) never added
+#else
+                if (fire[q]) {
+#endif
+                    unsafeAtomicAdd(phi + g_c[q], ph[q]);
+                    if (HEAT) unsafeAtomicAdd(heat + g_c[q], ht[q]);
+                }
+            }
+            phase_barrier<LDS_STAGE>();  // every wave has read the old values it needs
+#pragma unroll
+            for (int q = 0; q < P; q++)
+                if (woff[q] >= 0) C.stg.st((uint32_t)woff[q], cdo[q], wo[q]);
+            if (d1.n != n) {  // last phase of this plane: interpolation offsets of the next one
+                const double alam_next = cinterp_alam(n + 1);
+                for (int i = tid; i < 2 * W; i += SWEEP_THREADS) {
+                    if (i < W) du_tab[i] = interp_offsets(i, su, u0 + 1, alam_next);
+                    else dv_tab[i - W] = interp_offsets(i - W, sv, v0 + 1, alam_next);
+                }
+            }
+            phase_barrier<LDS_STAGE>();  // new values visible
+            // ---- rotate the pipeline --------------------------------------------------------------
+            d0 = d1;
+            d1 = d2;
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+                meta_c[q] = meta_n[q];
+                meta_n[q] = meta_nn[q];
+                geo_c[q] = geo_n[q];
+                nhi_c[q] = nhi_n[q];
+                g_c[q] = g_n[q];
             }
         }
     }
