@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--density", choices=["uniform", "clustered"], default="uniform")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-sources-per-core", type=int, default=6)
+    ap.add_argument("--cpu-sources-per-core", type=int, default=48)  # ~15 s of CPU work per core
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -195,7 +195,7 @@ def main():
                        "ns_per_source_per_sphere_cell": dt / a.steps / a.sources / (4.0 / 3.0 * np.pi * a.R ** 3) * 1e9,
                        "phi_checksum": checksum},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "asora::sweep_kernel",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "asora::sweep_tab_kernel" if info["table_driven"] else "asora::sweep_kernel",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes,
                          "launch": info},
         }
