@@ -473,9 +473,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
 #ifndef ASORA_GROUP
 #define ASORA_GROUP 1
 #endif
-// chunks per wave per phase: 1 keeps the kernel at 117 VGPRs (4 waves/SIMD without spills); measured best
+// chunks per wave per phase.  Measured on the 256^3 / R = 60 sweep (4 waves per SIMD): 3 > 1 > 2 > 4; with 3,
+// most planes (10 chunks on average) are done in one phase
 #ifndef ASORA_PHASE_CHUNKS
-#define ASORA_PHASE_CHUNKS 1
+#define ASORA_PHASE_CHUNKS 3
 #endif
 #ifndef ASORA_WAVES_PER_EU
 #define ASORA_WAVES_PER_EU 4
@@ -735,8 +736,6 @@ void sweep_tab_kernel(SweepArgs A) {
             }
 
             // ---- phase p: interpolation and rates from the old staged values ---------------------
-            // in stages over the P slots, so that the slots' dependency chains interleave and all
-            // table look-ups of the phase are in flight together
             const int n = d0.n;
             double cdo[P], wo[P], ph[P], ht[HEAT ? P : 1], cin[P];
             int woff[P];
@@ -793,19 +792,15 @@ void sweep_tab_kernel(SweepArgs A) {
 #endif
                 }
             }
-            RatePrep rp[P];
-            RateLoads rl[P];
-#pragma unroll
-            for (int q = 0; q < P; q++)
-                if (rate_slot[q]) rp[q] = rates_prepare(A, C.lg, flux, cin[q], cdo[q], geo_c[q].y);
-#pragma unroll
-            for (int q = 0; q < P; q++)
-                if (rate_slot[q]) rl[q] = rates_load<HEAT>(A, rp[q]);
+            // rates, one slot at a time (keeps the live registers low); the two look-ups of a cell are in
+            // flight together
 #pragma unroll
             for (int q = 0; q < P; q++)
                 if (rate_slot[q]) {
+                    const RatePrep rp = rates_prepare(A, C.lg, flux, cin[q], cdo[q], geo_c[q].y);
+                    const RateLoads rl = rates_load<HEAT>(A, rp);
                     double p_, h_ = 0.0;
-                    rates_finish<HEAT>(A, rp[q], rl[q], nhi_c[q], p_, h_);
+                    rates_finish<HEAT>(A, rp, rl, nhi_c[q], p_, h_);
                     ph[q] = p_;
                     if (HEAT) ht[q] = h_;
                 }

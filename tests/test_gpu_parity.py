@@ -110,6 +110,18 @@ def test_reference_fixture_photo_ionization_rate(asora, port_oracle):
     assert phi.max() == pytest.approx(2.7e-39, rel=0.1)  # magnitude quoted in SURVEY.md section 4
 
 
+@pytest.mark.parametrize("R", [0.0, 0.4, 1.0, 1.5, 2.0])
+def test_tiny_radius_vs_oracle(asora, port_oracle, R):
+    """R below one cell: only the source cell (and for R >= 1 its nearest neighbours) produce rates; the
+    octahedron degenerates to q_max = 0, 1, 2, 3, 4 shells."""
+    c = cases._base(12, R, 5e20, [[0, 11, 6], [3, 3, 3]], [1.0, 2.0], ndens=cases.lognormal_density(12, 4))
+    phi, cdh, _ = run_hip(asora, c)
+    o = cases.run_oracle(port_oracle, c, heat=False)
+    r = compare(phi, o["phi_ion"])
+    assert r["ok"] and r["support_equal"], r
+    assert (phi != 0).sum() >= 2
+
+
 def test_empty_source_list(asora, golden_dir):
     c = load_golden(golden_dir, "uniform32_center")
     phi, cdh, _ = run_hip(asora, c, num_src=0)
