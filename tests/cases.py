@@ -184,6 +184,22 @@ def evolve_case(N=32, seed=5):
     return c
 
 
+def evolve_case_shadow128():
+    """BASELINE config 3 (examples/paper_tests/test4_shadow): 128^3, cell 0.014 Mpc / 128,
+    one 1e49 s^-1 source at (64, 64, 64), ndens 1e-3 with a x6 over-dense sphere of radius 8 cells centred
+    (76, 76, 63) (0-based), xh0 = 1.2e-3, T = 1e4 K, black body 5e4 K, R_max = 150 cells (full box),
+    time steps of 1 Myr."""
+    N = 128
+    nd = np.full((N, N, N), 1e-3)
+    i, j, k = np.meshgrid(np.arange(N), np.arange(N), np.arange(N), indexing="ij")
+    nd[(i - 76) ** 2 + (j - 76) ** 2 + (k - 63) ** 2 <= 64] = 6e-3
+    c = _base(N, 150.0, 0.014 * MPC / 128, [[64, 64, 64]], [10.0], ndens=nd, xh=np.full((N, N, N), 1.2e-3),
+              table_kw=dict(numtau=10000))
+    c.update(CHEM)
+    c.update(dt=1e6 * YEAR, temp=np.full((N, N, N), 1e4), clump=np.ones((N, N, N)), convergence_fraction=1e-4)
+    return c
+
+
 def chemistry_case(N=24, seed=3):
     """Random per-cell inputs for one chemistry pass covering neutral .. fully ionised cells, zero and
     huge rates, temperatures 1e2 .. 1e5 K, clumping 1 .. 30, and a time average that differs from xh."""

@@ -92,3 +92,34 @@ def test_evolve_step_vs_golden(golden_dir):
     assert err <= 1e-8  # north_star bar; typically ~1e-13
     assert rel_phi <= 1e-8  # phi of the last iteration, computed from an xh_av that differs by ~1e-13
     assert cdh.shape == (N, N, N) and np.all(np.isfinite(cdh))
+
+
+def test_evolve_two_steps_shadow128_vs_oracle(port_oracle):
+    """BASELINE config 3: two consecutive evolve steps (raytrace + chemistry to convergence) of the 128^3
+    shadow test, device loop vs the same host loop driven by the CPU oracle.  Bar: xHII <= 1e-8."""
+    from evolve_host import evolve3D_host
+    from pyc2ray_amd import asora_core
+    from pyc2ray_amd.evolve import evolve3D
+    c = cases.evolve_case_shadow128()
+    N = c["N"]
+    xh_gpu, xh_cpu = c["xh"].copy(), c["xh"].copy()
+    asora_core.device_init(N, 8, 0, 1)
+    try:
+        asora_core.photo_table_to_device(c["thin"], c["thick"])
+        for step in range(2):
+            hist = []
+            xh_gpu, phi, _ = evolve3D(c["dt"], c["dr"], c["flux"], c["pos"].T, True, 0, 0, 0.0, False, None, 0, 1,
+                                      c["temp"], c["ndens"], xh_gpu, c["clump"], c["thin"], c["thick"],
+                                      c["minlogtau"], c["dlogtau"], c["R"], c["convergence_fraction"], c["sig"],
+                                      *[c[k] for k in CHEM_KEYS], history=hist, want_coldens=False)
+            ref = evolve3D_host(port_oracle, dict(c, xh=xh_cpu))
+            xh_cpu = ref["xh_new"]
+            err = np.max(np.abs(xh_gpu - xh_cpu))
+            print(f"[shadow128 step {step}] niter {len(hist)} (oracle {ref['niter']})  mean xHII {xh_gpu.mean():.4e}  "
+                  f"max|d xHII| {err:.2e}")
+            assert len(hist) == ref["niter"]
+            assert err <= 1e-8
+    finally:
+        asora_core.device_close()
+    # the clump casts a shadow: cells behind it stay more neutral than their mirror images
+    assert xh_gpu[90, 90, 63] < xh_gpu[38, 38, 65]
