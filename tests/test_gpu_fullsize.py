@@ -106,3 +106,100 @@ def test_flux_linearity_and_translation_256(asora):
     # not bit-exact: the interpolation carries the absolute source coordinate (raytracing.f90:683), and a
     # 1e-16 change of a column density is a tau * 1e-16 relative change of the rate (tau reaches ~250 here)
     assert np.array_equal(phi3 != 0, m) and np.max(np.abs(phi3[m] / ref[m] - 1.0)) <= 1e-8
+
+
+def test_config0_single_source_128_vs_oracle(asora, port_oracle):
+    """BASELINE configs[0] (examples/unit_tests_hackathon/1_single_black_body): one 1e49 s^-1 source at
+    1-based (96, 96, 64) in a uniform 128^3 box, black body 5e4 K, R_max = 150 cells (full box)."""
+    N = 128
+    c = cases._base(N, 150.0, 0.014 * MPC / 128, [[95, 95, 63]], [10.0], xh=np.full((N, N, N), 1.2e-3),
+                    table_kw=dict(numtau=10000))
+    phi, cdh, _ = run_hip(asora, c)
+    o = cases.run_oracle(port_oracle, c, heat=False, sens=True)
+    r = compare(phi, o["phi_ion"], sens=o["phi_sens"])
+    print(f"\n[config0 128] max_rel={r['max_rel']:.3e} n_sens={r['n_sens']} support_equal={r['support_equal']}")
+    assert r["ok"] and r["support_equal"] and (phi > 0).all(), r
+    assert np.array_equal(cdh, o["coldensh_out"])
+
+
+def tiled_lognormal(N, tile, seed):
+    reps = -(-N // tile)
+    return np.ascontiguousarray(np.tile(cases.lognormal_density(tile, seed, smooth=2.0), (reps, reps, reps))[:N, :N, :N])
+
+
+def clustered_sources(ndens, ns, seed):
+    p = (ndens ** 2).ravel()
+    idx = np.random.default_rng(seed).choice(p.size, size=ns, p=p / p.sum())
+    return np.stack(np.unravel_index(idx, ndens.shape), axis=1).astype(np.int32)
+
+
+def run_shards(asora, c, shards):
+    """phi of each contiguous source shard (what each rank of a multi-GPU run computes before the all-reduce)."""
+    N = c["N"]
+    out = []
+    asora.device_init(N, 64, 0, 1)
+    try:
+        asora.photo_table_to_device(c["thin"], c["thick"], int(c["num_tau"]))
+        asora.density_to_device(np.ravel(c["ndens"]).copy(), N)
+        xh = np.ravel(c["xh"]).copy()
+        for lo, hi in shards:
+            asora.source_data_to_device(np.ascontiguousarray(c["pos"][lo:hi].ravel()),
+                                        np.ascontiguousarray(c["flux"][lo:hi]), hi - lo)
+            cdh, phi = np.zeros(N ** 3), np.zeros(N ** 3)
+            asora.do_all_sources(c["R"], cdh, c["sig"], c["dr"], None, xh, phi, hi - lo, N, c["minlogtau"],
+                                 c["dlogtau"], int(c["num_tau"]))
+            out.append(phi.reshape(N, N, N))
+    finally:
+        asora.device_close()
+    return out
+
+
+def test_config3_eor250_sharded(asora, port_oracle):
+    """BASELINE configs[3] stand-in: N = 250 (even, not a power of two), log-normal density,
+    halo-like sources drawn ~ ndens^2 (many share a cell), non-integer R = 58.6.  (i) the first sources
+    against the oracle; (ii) the 8-way contiguous shards of pyc2ray/evolve.py:175-186 sum to the
+    single-call result -- the multi-GPU decomposition minus the transport."""
+    from pyc2ray_amd.sourceutils import shard_sources
+    N, ns = 250, 16000
+    nd = tiled_lognormal(N, 125, 7)
+    pos = clustered_sources(nd, ns, 11)
+    flux = np.random.default_rng(5).uniform(0.01, 5.0, ns)
+    c = cases._base(N, 60.0 * 250 / 256, 3.0 * MPC / 200, pos, flux, ndens=nd, xh=np.full((N, N, N), 2e-4),
+                    table_kw=dict(temp=1e5, numtau=20000))
+    c8 = dict(c, pos=pos[:8], flux=flux[:8])
+    phi8, _, _ = run_hip(asora, c8)
+    box = int(np.ceil(c["R"]))
+    o = cases.run_oracle(port_oracle, c8, heat=False, sens=True, max_subbox=box, subboxsize=box)
+    r = compare(phi8, o["phi_ion"], sens=o["phi_sens"])
+    print(f"\n[eor250 8 sources] max_rel={r['max_rel']:.3e} n_sens={r['n_sens']} frac_floor={r['frac_floor']:.2e}")
+    assert r["ok"] and r["support_equal"], r
+    shards = [shard_sources(ns, rk, 8) for rk in range(8)]
+    assert shards[0] == (0, 2000) and shards[-1] == (14000, 16000)
+    parts = run_shards(asora, c, [(0, ns)] + shards)
+    full, summed = parts[0], sum(parts[1:])
+    m = full > 0
+    rel = np.max(np.abs(summed[m] / full[m] - 1.0))
+    print(f"[eor250 {ns} sources] 8-shard sum vs single call: max rel {rel:.2e}, cells covered {m.mean():.3f}")
+    assert np.array_equal(summed > 0, m) and rel <= 1e-12
+
+
+def test_config4_stress512(asora, port_oracle):
+    """BASELINE configs[4] stand-in: 512^3 log-normal grid (1 GiB per grid), R = 60: parity on a few sources,
+    then a 4000-source call as a capacity / addressing check (positive rates inside the box only)."""
+    N = 512
+    nd = tiled_lognormal(N, 128, 3)
+    pos = clustered_sources(nd, 4000, 13)
+    flux = np.random.default_rng(6).uniform(0.01, 5.0, 4000)
+    c = cases._base(N, 60.0, 3.0 * MPC / 200, pos, flux, ndens=nd, xh=np.full((N, N, N), 2e-4),
+                    table_kw=dict(temp=1e5, numtau=20000))
+    c4 = dict(c, pos=pos[:4], flux=flux[:4])
+    phi4, cdh4, _ = run_hip(asora, c4)
+    o = cases.run_oracle(port_oracle, c4, heat=False, sens=True, max_subbox=60, subboxsize=60)
+    r = compare(phi4, o["phi_ion"], sens=o["phi_sens"])
+    print(f"\n[stress512 4 sources] max_rel={r['max_rel']:.3e} n_sens={r['n_sens']} frac_floor={r['frac_floor']:.2e}")
+    assert r["ok"] and r["support_equal"], r
+    del o
+    phi, = run_shards(asora, c, [(0, 4000)])
+    assert np.isfinite(phi).all() and (phi >= 0).all() and (phi > 0).mean() > 0.5
+    # every source cell received its own (largest nearby) contribution
+    assert (phi[pos[:, 0], pos[:, 1], pos[:, 2]] > 0).all()
