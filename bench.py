@@ -75,6 +75,13 @@ def cpu_baseline(a):
                        f"processes x {a.cpu_sources_per_core} sources, raytrace time {r['seconds']:.1f} s")}
 
 
+def _mark(msg):
+    if os.environ.get("ASORA_BENCH_DEBUG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(45, exit=False, file=sys.stderr)  # where is it, if it stops moving
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,11 +112,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the ASORA path)")
-    torch.cuda.set_device(local_rank)
+    # one GPU per rank; ranks wrap around only in single-GPU rehearsals of the N > 1 path
+    # (ASORA_BENCH_BACKEND=gloo, since RCCL refuses two ranks on one device)
+    ngpu = torch.cuda.device_count()
+    dev_index = local_rank % ngpu
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("ASORA_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
+    _mark("process group ready")
     from pyc2ray_amd import libasora as asora
     from pyc2ray_amd.sourceutils import shard_sources
 
@@ -119,7 +135,7 @@ def main():
     N = a.N
     lo, hi = shard_sources(a.sources, rank, world)
     ns_local = hi - lo
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
     ndens_t = torch.from_numpy(inp["ndens"].ravel()).to(dev)
     xh_t = torch.from_numpy(inp["xh"].ravel()).to(dev)
     phi_t = torch.zeros(N ** 3, dtype=torch.float64, device=dev)
@@ -127,7 +143,7 @@ def main():
     for kv in filter(None, os.environ.get("ASORA_OPTIONS", "").split(",")):  # tuning experiments: name=value,...
         k, v = kv.split("=")
         asora.set_option(k, int(v))
-    asora.device_init(N, 64, local_rank, torch.cuda.device_count())
+    asora.device_init(N, 64, dev_index, ngpu)
     asora.photo_table_to_device(np.ascontiguousarray(inp["thin"]), np.ascontiguousarray(inp["thick"]),
                                 inp["thin"].shape[0])
     asora.density_from_device(ndens_t.data_ptr(), N)
@@ -140,7 +156,12 @@ def main():
         asora.do_all_sources_dev(a.R, 0, 6.30e-18, a.dr, xh_t.data_ptr(), phi_t.data_ptr(), 0, ns_local, N, -20.0,
                                  inp["dlogtau"], num_tau, stream)
         if world > 1:
-            dist.all_reduce(phi_t)  # RCCL sum over xGMI, in place on device memory
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(phi_t)  # RCCL sum over xGMI, in place on device memory
+            else:  # single-GPU rehearsal only: through the host
+                h = phi_t.cpu()
+                dist.all_reduce(h)
+                phi_t.copy_(h)
 
     def fence():
         torch.cuda.synchronize()
@@ -148,16 +169,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    _mark("inputs on device")
     for _ in range(a.warmup):
         step()
+    _mark("warm-up issued")
     fence()
+    _mark("warm-up done")
     kern_ms = []
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
         step()
+        _mark(f"step {i} issued")
         kern_ms.append(asora.last_sweep_ms())  # HIP events on the launch stream (waits for the sweep)
+        _mark(f"step {i} timed")
     fence()
     dt = time.perf_counter() - t0
+    _mark("timed steps done")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
