@@ -190,7 +190,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    visits, in_sphere = asora.visit_count(a.R, N)
+    visits, _ = asora.visit_count(a.R, N)
+    in_sphere = asora.geometry_census(a.R, a.dr, N)["owned_rate"]  # the oracle's floating-point sphere test
     total_visits = float(visits) * a.sources
     value = total_visits * a.steps / dt
     k_ms = float(np.mean(kern_ms))

@@ -116,6 +116,15 @@ int asora_test_cinterp_ex(const int32_t pos0[3], const double *dens, int N, doub
  * src/asora/raytracing.cu:110,140-141,214-255,320.  Pure host arithmetic. */
 int asora_visit_count(double R, int m1, long long *visits, long long *in_sphere);
 
+/* Host-side self-check of the sweep's cell tables (no device needed): builds the geometry tables of
+ * (m1, R, dr) exactly as a do_all_sources call would and counts, over the 24 sectors of one source, the
+ * cells that are OWNED (produce output) -- must equal asora_visit_count's `visits` --, the owned cells
+ * inside the R sphere by the oracle's floating-point predicate, and all cells computed (owned + the
+ * sector-boundary cells recomputed by neighbouring sectors).  Also returns the staged pairs per task and
+ * the number of distinct geometry variants. */
+int asora_geometry_census(double R, double dr, int m1, long long *owned, long long *owned_rate, long long *computed,
+                          int *staging_entries, int *variants);
+
 /* Duration of the raytracing sweep kernel of the last do_all_sources* call, from HIP events
  * recorded on the launch stream (synchronises on the stop event). */
 int asora_last_sweep_ms(float *ms);

@@ -169,17 +169,24 @@ int packed_layout(int q_max, int nmaxmax, int LU, int LV, std::vector<int> &rowo
     return rowoff[LU + 2];
 }
 
-int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r, hipStream_t st) {
-    if (S.geo_valid && S.geo_N == N && S.geo_R == R && S.geo_dr == dr) return 0;
-    if (S.geo_valid) HIP_TRY(hipStreamSynchronize(st));  // tables may still be in use by a previous launch
-    free_geometry();
+struct HostGeometry {
+    std::vector<asora::PlaneInfo> planes;  // [variant][nplanes]
+    std::vector<uint2> meta;
+    std::vector<double2> geo;
+    int vmap[8] = {0};
+    int nplanes = 0, nvariants = 0, entries_max = 0;
+};
+
+// Pure host arithmetic (no device needed): also what asora_geometry_census counts.
+void make_geometry(int N, double R, double dr, int q_max, int last_l, int last_r, HostGeometry &G) {
+    (void)N;
     const int nmaxmax = std::min(std::max(last_l, last_r), q_max);
     const int nplanes = nmaxmax + 1;
     const int cap = plane_extent(q_max, last_l, last_r);
     const double R2 = R * R, dr2 = dr * dr;
-    std::vector<asora::PlaneInfo> planes;
-    std::vector<uint2> meta;
-    std::vector<double2> geo;
+    std::vector<asora::PlaneInfo> &planes = G.planes;
+    std::vector<uint2> &meta = G.meta;
+    std::vector<double2> &geo = G.geo;
     std::vector<std::array<int, 3>> keys;  // (LU, LV, order)
     std::vector<int> rowoff;
     int entries_max = 0;
@@ -189,8 +196,8 @@ int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
         int found = -1;
         for (size_t k = 0; k < keys.size(); k++)
             if (keys[k][0] == LU && keys[k][1] == LV && keys[k][2] == order) found = (int)k;
-        if (found >= 0) { S.geo_vmap[code] = found; continue; }
-        S.geo_vmap[code] = (int)keys.size();
+        if (found >= 0) { G.vmap[code] = found; continue; }
+        G.vmap[code] = (int)keys.size();
         keys.push_back({LU, LV, order});
         const int entries = packed_layout(q_max, nmaxmax, LU, LV, rowoff);
         entries_max = std::max(entries_max, entries);
@@ -234,14 +241,26 @@ int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
         }
     }
     if (meta.empty()) { meta.push_back(uint2{0, 0}); geo.push_back(double2{0, 0}); }
-    HIP_TRY(hipMalloc(&S.planes_dev, planes.size() * sizeof(asora::PlaneInfo)));
-    HIP_TRY(hipMalloc(&S.cell_meta_dev, meta.size() * sizeof(uint2)));
-    HIP_TRY(hipMalloc(&S.cell_geo_dev, geo.size() * sizeof(double2)));
+    G.nplanes = nplanes;
+    G.nvariants = (int)keys.size();
+    G.entries_max = entries_max;
+}
+
+int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r, hipStream_t st) {
+    if (S.geo_valid && S.geo_N == N && S.geo_R == R && S.geo_dr == dr) return 0;
+    if (S.geo_valid) HIP_TRY(hipStreamSynchronize(st));  // tables may still be in use by a previous launch
+    free_geometry();
+    HostGeometry G;
+    make_geometry(N, R, dr, q_max, last_l, last_r, G);
+    HIP_TRY(hipMalloc(&S.planes_dev, G.planes.size() * sizeof(asora::PlaneInfo)));
+    HIP_TRY(hipMalloc(&S.cell_meta_dev, G.meta.size() * sizeof(uint2)));
+    HIP_TRY(hipMalloc(&S.cell_geo_dev, G.geo.size() * sizeof(double2)));
     // synchronous copies: the host vectors die at the end of this function
-    HIP_TRY(hipMemcpy(S.planes_dev, planes.data(), planes.size() * sizeof(asora::PlaneInfo), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(S.cell_meta_dev, meta.data(), meta.size() * sizeof(uint2), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(S.cell_geo_dev, geo.data(), geo.size() * sizeof(double2), hipMemcpyHostToDevice));
-    S.geo_N = N; S.geo_R = R; S.geo_dr = dr; S.geo_nplanes = nplanes; S.geo_entries = entries_max; S.geo_valid = true;
+    HIP_TRY(hipMemcpy(S.planes_dev, G.planes.data(), G.planes.size() * sizeof(asora::PlaneInfo), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(S.cell_meta_dev, G.meta.data(), G.meta.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(S.cell_geo_dev, G.geo.data(), G.geo.size() * sizeof(double2), hipMemcpyHostToDevice));
+    for (int i = 0; i < 8; i++) S.geo_vmap[i] = G.vmap[i];
+    S.geo_N = N; S.geo_R = R; S.geo_dr = dr; S.geo_nplanes = G.nplanes; S.geo_entries = G.entries_max; S.geo_valid = true;
     return 0;
 }
 
@@ -693,6 +712,36 @@ int asora_visit_count(double R, int m1, long long *visits, long long *in_sphere)
         }
     *visits = v;
     *in_sphere = s;
+    return 0;
+}
+
+int asora_geometry_census(double R, double dr, int m1, long long *owned, long long *owned_rate, long long *computed,
+                          int *staging_entries, int *variants) {
+    if (m1 < 2 || !(dr > 0.0) || !(R >= 0.0) || !owned || !owned_rate || !computed || !staging_entries || !variants)
+        return fail(9, "asora_geometry_census: bad arguments");
+    const int q_max = compute_q_max(R, m1);
+    const int last_r = m1 / 2 - 1 + m1 % 2, last_l = m1 / 2;
+    HostGeometry G;
+    make_geometry(m1, R, dr, q_max, last_l, last_r, G);
+    long long own = 1, rate = 1, comp = 24;  // the source cell: owned (and rated) once, staged by every sector
+    for (int t = 0; t < asora::SECTORS; t++) {
+        const int axis = t >> 3, sp = (t & 4) ? -1 : 1, su = (t & 2) ? -1 : 1, sv = (t & 1) ? -1 : 1;
+        const uint32_t ghostmask = (su < 0 ? asora::FLAG_A0 : 0u) | (sv < 0 ? asora::FLAG_B0 : 0u) |
+                                   (axis >= 1 ? asora::FLAG_BN : 0u) | (axis == 2 ? asora::FLAG_AN : 0u);
+        const int nmax = std::min(sp > 0 ? last_r : last_l, q_max);
+        const int variant = G.vmap[(((su < 0) ? 2 : 0) + ((sv < 0) ? 1 : 0)) * 2 + (axis != 0 ? 1 : 0)];
+        const asora::PlaneInfo *pl = G.planes.data() + (size_t)variant * G.nplanes;
+        for (int n = 1; n <= nmax; n++)
+            for (uint32_t i = 0; i < pl[n].cntT; i++) {
+                const uint32_t fl = G.meta[pl[n].off + i].x >> asora::META_FLAG_SHIFT;
+                comp++;
+                if (fl & ghostmask) continue;
+                own++;
+                if (i < pl[n].cntA) rate++;
+            }
+    }
+    *owned = own; *owned_rate = rate; *computed = comp;
+    *staging_entries = G.entries_max; *variants = G.nvariants;
     return 0;
 }
 

@@ -45,6 +45,8 @@ ABI = {
     "asora_test_cinterp": (C.c_int, [_ip, _dp, C.c_int, _dp, C.c_int]),
     "asora_test_cinterp_ex": (C.c_int, [_ip, _dp, C.c_int, C.c_double, C.c_int, C.c_int, _dp, C.c_int]),
     "asora_visit_count": (C.c_int, [C.c_double, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "asora_geometry_census": (C.c_int, [C.c_double, C.c_double, C.c_int] + [C.POINTER(C.c_longlong)] * 3 +
+                              [C.POINTER(C.c_int)] * 2),
     "asora_last_sweep_ms": (C.c_int, [C.POINTER(C.c_float)]),
     "asora_last_launch_info": (C.c_int, [C.POINTER(C.c_int)] * 4),
     "asora_set_option": (C.c_int, [C.c_char_p, C.c_longlong]),
@@ -223,6 +225,15 @@ def visit_count(R, m1):
     v, s = C.c_longlong(), C.c_longlong()
     _check(_lib.asora_visit_count(float(R), int(m1), C.byref(v), C.byref(s)))
     return v.value, s.value
+
+
+def geometry_census(R, dr, m1):
+    """Host-side census of the sweep's cell tables: dict(owned, owned_rate, computed, staging_entries, variants)."""
+    a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+    e, v = C.c_int(), C.c_int()
+    _check(_lib.asora_geometry_census(float(R), float(dr), int(m1), C.byref(a), C.byref(b), C.byref(c), C.byref(e),
+                                      C.byref(v)))
+    return dict(owned=a.value, owned_rate=b.value, computed=c.value, staging_entries=e.value, variants=v.value)
 
 
 def set_option(name, value):

@@ -104,3 +104,47 @@ def test_graft_entry_build_is_idempotent():
     import __graft_entry__ as g
     before = os.path.getmtime(g.build_hip())
     assert os.path.getmtime(g.build_hip()) == before
+
+
+@pytest.mark.parametrize("N,R,dr", [(256, 60.0, 4.6285e22), (32, 7.3, 1.0), (33, 100.0, 3.0e20), (32, 100.0, 3.0e20),
+                                    (50, 15.0, 3.0857e18), (12, 0.4, 5e20), (64, 31.9, 1.0), (250, 58.59375, 4.6e22),
+                                    (128, 150.0, 3.37e20)])
+def test_geometry_tables_cover_every_visit_exactly_once(port_oracle, N, R, dr):
+    """Host logic of the table-driven sweep (no GPU): over the 24 sectors of a source the OWNED cells of
+    the geometry tables are exactly the reference's visit set (octahedron(q_max) within the box limits), the
+    rate-producing ones exactly those inside the R sphere."""
+    from pyc2ray_amd import libasora
+    c = libasora.geometry_census(R, dr, N)
+    visits, in_sphere_int = port_oracle.asora_visit_count(R, N)
+    assert c["owned"] == visits
+    # the sphere test in the oracle's own floating-point form (raytracing.f90:448-451,474): for integer R and
+    # dr != 1 the cells with d^2 == R^2 sit on a rounding knife-edge (SURVEY.md 3.4 #11)
+    q_max = int(np.ceil(1.73205080757 * min(R, 1.73205080757 * N / 2.0)))
+    ax = np.arange(-(N // 2), N // 2 - 1 + N % 2 + 1)
+    i, j, k = np.meshgrid(ax, ax, ax, indexing="ij")
+    octa = np.abs(i) + np.abs(j) + np.abs(k) <= q_max
+    xs, ys, zs = dr * i.astype(np.float64), dr * j.astype(np.float64), dr * k.astype(np.float64)
+    dist2 = xs * xs + ys * ys + zs * zs
+    in_sphere = int(np.count_nonzero(octa & ~(dist2 / (dr * dr) > R * R)))
+    assert octa.sum() == visits and abs(in_sphere - in_sphere_int) <= 200
+    assert c["owned_rate"] == in_sphere
+    assert visits <= c["computed"] <= 1.5 * visits + 48  # sector-boundary cells are recomputed, nothing else
+    assert 0 < c["staging_entries"] <= 65535 and 1 <= c["variants"] <= 8
+
+
+def test_merge_and_bin_sources():
+    from pyc2ray_amd.sourceutils import bin_sources, merge_sources
+    pos = np.array([[3, 3, 1, 3], [4, 4, 0, 4], [5, 5, 2, 6]])
+    p, f = merge_sources(pos, np.array([1.0, 2.0, 4.0, 8.0]))
+    assert p.shape == (3, 3) and f.sum() == 15.0
+    assert sorted(f.tolist()) == [3.0, 4.0, 8.0]
+    assert f[np.all(p.T == [3, 4, 5], axis=1)][0] == 3.0
+    rng = np.random.default_rng(0)
+    xyz = rng.uniform(0, 10.0, (500, 3))
+    xyz[0] = [10.0, 0.0, 5.0]  # on the closed upper edge
+    m = rng.uniform(1, 2, 500)
+    sp, sm = bin_sources(xyz, m, 10.0, 8)
+    ref = np.zeros((8, 8, 8))
+    ii = np.minimum((xyz / 10.0 * 8).astype(int), 7)
+    np.add.at(ref, (ii[:, 0], ii[:, 1], ii[:, 2]), m)
+    assert np.array_equal(sp, np.argwhere(ref > 0)) and np.allclose(sm, ref[ref > 0], rtol=1e-14)
