@@ -473,10 +473,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
 #ifndef ASORA_GROUP
 #define ASORA_GROUP 1
 #endif
-// chunks per wave per phase.  Measured on the 256^3 / R = 60 sweep (4 waves per SIMD): 3 > 1 > 2 > 4; with 3,
-// most planes (10 chunks on average) are done in one phase
+// chunks per wave per phase.  Measured on the 256^3 / R = 60 sweep (4 waves per SIMD, ms per 1e4 sources):
+// 1: 135, 2: 121 (122 VGPRs, no spills), 3: 122, 4: 292 (spills)
 #ifndef ASORA_PHASE_CHUNKS
-#define ASORA_PHASE_CHUNKS 3
+#define ASORA_PHASE_CHUNKS 2
 #endif
 #ifndef ASORA_WAVES_PER_EU
 #define ASORA_WAVES_PER_EU 4
@@ -578,11 +578,11 @@ __device__ __forceinline__ uint32_t slot_index(const PhaseDesc &d, int wave, int
 // The sweep is latency-bound (rocprofv3: waves wait 73 % of their cycles; an ablation without the
 // f64 atomics runs 30 % faster, without barriers only 5 %), so the memory operations of a phase are
 // issued one to two phases ahead, in plain C++ (the compiler keeps the s_waitcnt bookkeeping):
-//     top of phase p : geometry + neutral density of phase p+1 (their addresses need the cell
-//                      coordinates of p+1, loaded during phase p-1), cell coordinates of phase p+2
-//     phase p        : staging reads, interpolation, rates; the rates' table look-ups are the only
-//                      point where the wave drains its memory counter, and everything in flight
-//                      there was issued at least one interpolation pass earlier
+//     top of phase p : cell coordinates of phase p+1
+//     phase p        : staging reads and interpolation of all slots; then geometry + neutral density of
+//                      phase p+1 (their addresses need its cell coordinates, which have landed behind
+//                      the interpolation); then the rates, whose table look-ups are the only point where
+//                      the wave drains its memory counter
 //     end of phase p : all f64 atomics of the phase in one burst (they complete behind the
 //                      barriers and the next phase's interpolation), barrier, deferred staging
 //                      writes, barrier.  The barriers wait for LDS traffic only.
@@ -649,8 +649,8 @@ void sweep_tab_kernel(SweepArgs A) {
         __syncthreads();
         const uint32_t pos00 = planes[0].off;  // staging position of cell (0, 0) in this variant's layout
 
-        // phase descriptors of p, p+1, p+2 and the cell coordinates of p and p+1
-        PhaseDesc d0, d1, d2;
+        // phase descriptors of p and p+1, cell coordinates of p
+        PhaseDesc d0, d1;
         d0.n = 1; d0.jbase = 0; d0.off = 0; d0.cntA = d0.cntT = d0.nchunkA = d0.nchunkB = 0;
         phase_load_plane(d0, planes, nmax);
         d1 = phase_next<NW * P>(d0, planes, nmax);
@@ -659,7 +659,6 @@ void sweep_tab_kernel(SweepArgs A) {
         for (int q = 0; q < P; q++) {
             bool v, ia;
             meta_c[q] = A.cell_meta[d0.off + slot_index<NW>(d0, wave, q, lane, v, ia)];
-            meta_n[q] = A.cell_meta[d1.off + slot_index<NW>(d1, wave, q, lane, v, ia)];
         }
 
         // (the previous task's last barrier guarantees nobody still reads the arrays below)
@@ -712,26 +711,14 @@ void sweep_tab_kernel(SweepArgs A) {
         }
 
         while (d0.valid) {
-            // ---- issue the loads of the coming phases -------------------------------------------
-            d2 = phase_next<NW * P>(d1, planes, nmax);
-            uint2 meta_nn[P];
+            // ---- cell coordinates of the next phase: in flight during this phase's interpolation ------
+            uint32_t idx_n[P];
             if (d1.valid) {
-                const uint32_t baseP = (uint32_t)wrap(p0 + sp * d1.n, N) * strideP;
 #pragma unroll
                 for (int q = 0; q < P; q++) {
                     bool v, ia;
-                    const uint32_t idx = slot_index<NW>(d1, wave, q, lane, v, ia);
-                    const uint32_t a = meta_n[q].x & META_COORD_MASK, b = (meta_n[q].x >> META_COORD_BITS) & META_COORD_MASK;
-                    g_n[q] = baseP + (uint32_t)rowU[a] + (uint32_t)colV[b];
-                    geo_n[q] = A.cell_geo[d1.off + idx];
-                    nhi_n[q] = nhi[g_n[q]];
-                }
-            }
-            if (d2.valid) {
-#pragma unroll
-                for (int q = 0; q < P; q++) {
-                    bool v, ia;
-                    meta_nn[q] = A.cell_meta[d2.off + slot_index<NW>(d2, wave, q, lane, v, ia)];
+                    idx_n[q] = d1.off + slot_index<NW>(d1, wave, q, lane, v, ia);
+                    meta_n[q] = A.cell_meta[idx_n[q]];
                 }
             }
 
@@ -792,6 +779,17 @@ void sweep_tab_kernel(SweepArgs A) {
 #endif
                 }
             }
+            // ---- geometry + neutral density of the next phase: in flight during this phase's rates ------
+            if (d1.valid) {
+                const uint32_t baseP = (uint32_t)wrap(p0 + sp * d1.n, N) * strideP;
+#pragma unroll
+                for (int q = 0; q < P; q++) {
+                    const uint32_t a = meta_n[q].x & META_COORD_MASK, b = (meta_n[q].x >> META_COORD_BITS) & META_COORD_MASK;
+                    g_n[q] = baseP + (uint32_t)rowU[a] + (uint32_t)colV[b];
+                    geo_n[q] = A.cell_geo[idx_n[q]];
+                    nhi_n[q] = nhi[g_n[q]];
+                }
+            }
             // rates, one slot at a time (keeps the live registers low); the two look-ups of a cell are in
             // flight together
 #pragma unroll
@@ -830,11 +828,10 @@ void sweep_tab_kernel(SweepArgs A) {
             phase_barrier<LDS_STAGE>();  // new values visible
             // ---- rotate the pipeline --------------------------------------------------------------
             d0 = d1;
-            d1 = d2;
+            d1 = phase_next<NW * P>(d1, planes, nmax);
 #pragma unroll
             for (int q = 0; q < P; q++) {
                 meta_c[q] = meta_n[q];
-                meta_n[q] = meta_nn[q];
                 geo_c[q] = geo_n[q];
                 nhi_c[q] = nhi_n[q];
                 g_c[q] = g_n[q];
