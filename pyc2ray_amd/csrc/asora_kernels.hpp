@@ -210,9 +210,10 @@ __device__ __forceinline__ RatePrep rates_prepare(const SweepArgs &A, Log10LDS l
     return r;
 }
 __device__ __forceinline__ double2 table_pair(const double *__restrict__ t, int i0) {
+    const char *p = reinterpret_cast<const char *>(t) + (uint32_t)i0 * 8u;  // SGPR base + 32-bit offset
     double2 v;
-    v.x = t[i0];
-    v.y = t[i0 + 1];
+    v.x = *reinterpret_cast<const double *>(p);
+    v.y = *reinterpret_cast<const double *>(p + 8);
     return v;
 }
 template <bool HEAT>
@@ -482,6 +483,18 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
 #define ASORA_WAVES_PER_EU 4
 #endif
 
+// Element access at a 32-bit BYTE offset from a wave-uniform base: lets the compiler use the
+// "SGPR base + 32-bit VGPR offset" addressing mode instead of forming a 64-bit address per lane.
+// (the table-driven kernel only runs when every grid fits 2^31 bytes: host check `cells < 2^28`)
+template <typename T>
+__device__ __forceinline__ const T &at_byte(const T *base, uint32_t byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ T *ptr_byte(T *base, uint32_t byte_off) {
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off);
+}
+
 // cell_meta.x
 constexpr uint32_t META_COORD_BITS = 10, META_COORD_MASK = (1u << META_COORD_BITS) - 1;
 constexpr uint32_t META_FLAG_SHIFT = 2 * META_COORD_BITS;
@@ -658,7 +671,7 @@ void sweep_tab_kernel(SweepArgs A) {
 #pragma unroll
         for (int q = 0; q < P; q++) {
             bool v, ia;
-            meta_c[q] = A.cell_meta[d0.off + slot_index<NW>(d0, wave, q, lane, v, ia)];
+            meta_c[q] = at_byte(A.cell_meta, (d0.off + slot_index<NW>(d0, wave, q, lane, v, ia)) * 8u);
         }
 
         // (the previous task's last barrier guarantees nobody still reads the arrays below)
@@ -705,8 +718,8 @@ void sweep_tab_kernel(SweepArgs A) {
                 const uint32_t idx = slot_index<NW>(d0, wave, q, lane, v, ia);
                 const uint32_t a = meta_c[q].x & META_COORD_MASK, b = (meta_c[q].x >> META_COORD_BITS) & META_COORD_MASK;
                 g_c[q] = baseP + (uint32_t)rowU[a] + (uint32_t)colV[b];
-                geo_c[q] = A.cell_geo[d0.off + idx];
-                nhi_c[q] = nhi[g_c[q]];
+                geo_c[q] = at_byte(A.cell_geo, (d0.off + idx) * 16u);
+                nhi_c[q] = at_byte(nhi, g_c[q] * 8u);
             }
         }
 
@@ -718,7 +731,7 @@ void sweep_tab_kernel(SweepArgs A) {
                 for (int q = 0; q < P; q++) {
                     bool v, ia;
                     idx_n[q] = d1.off + slot_index<NW>(d1, wave, q, lane, v, ia);
-                    meta_n[q] = A.cell_meta[idx_n[q]];
+                    meta_n[q] = at_byte(A.cell_meta, idx_n[q] * 8u);
                 }
             }
 
@@ -770,7 +783,7 @@ void sweep_tab_kernel(SweepArgs A) {
                     woff[q] = valid ? (int)o_cur + 1 : -1;
                     const bool ghost = ((m.x >> META_FLAG_SHIFT) & ghostmask) != 0;
                     const bool own = valid && !ghost;
-                    if (cdh && own) cdh[g_c[q]] = c_out;
+                    if (cdh && own) *ptr_byte(cdh, g_c[q] * 8u) = c_out;
 #ifdef ASORA_ABL_NORATES
                     fire[q] = own && isA && cdh_in == 1.2345e300;  // ablation build: column densities only
                     rate_slot[q] = false;
@@ -786,8 +799,8 @@ void sweep_tab_kernel(SweepArgs A) {
                 for (int q = 0; q < P; q++) {
                     const uint32_t a = meta_n[q].x & META_COORD_MASK, b = (meta_n[q].x >> META_COORD_BITS) & META_COORD_MASK;
                     g_n[q] = baseP + (uint32_t)rowU[a] + (uint32_t)colV[b];
-                    geo_n[q] = A.cell_geo[idx_n[q]];
-                    nhi_n[q] = nhi[g_n[q]];
+                    geo_n[q] = at_byte(A.cell_geo, idx_n[q] * 16u);
+                    nhi_n[q] = at_byte(nhi, g_n[q] * 8u);
                 }
             }
             // rates, one slot at a time (keeps the live registers low); the two look-ups of a cell are in
@@ -810,8 +823,8 @@ void sweep_tab_kernel(SweepArgs A) {
 #else
                 if (fire[q]) {
 #endif
-                    unsafeAtomicAdd(phi + g_c[q], ph[q]);
-                    if (HEAT) unsafeAtomicAdd(heat + g_c[q], ht[q]);
+                    unsafeAtomicAdd(ptr_byte(phi, g_c[q] * 8u), ph[q]);
+                    if (HEAT) unsafeAtomicAdd(ptr_byte(heat, g_c[q] * 8u), ht[q]);
                 }
             }
             phase_barrier<LDS_STAGE>();  // every wave has read the old values it needs
