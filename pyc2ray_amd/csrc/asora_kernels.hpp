@@ -516,22 +516,11 @@ struct StageCW {
     }
 };
 
-// Everything the cells of one plane of one task share.
+// Staging array + log10 table of one workgroup.
 template <bool LDS_STAGE>
 struct PlaneCtx {
     StageCW<LDS_STAGE> stg;
     Log10LDS lg;
-    const double *__restrict__ nhi;
-    double *__restrict__ phi;
-    double *__restrict__ heat;
-    double *__restrict__ cdh;  // null unless this task exports its column density
-    const uint2 *__restrict__ meta;  // tables of the current plane
-    const double2 *__restrict__ geo;
-    const double2 *du, *dv;          // LDS: {d, 1 - d} per row / per column of the current plane
-    const int *rowU, *colV;          // LDS: wrapped grid offsets per row / per column
-    uint32_t baseP, ghostmask;
-    double flux;
-    int n, cntA, cntT, nchunkA, nchunkB;
 };
 
 // raytracing.f90:683-700 for one row (or column): x1 = 1-based source coordinate, s = sign
