@@ -133,7 +133,9 @@ int asora_last_sweep_ms(float *ms);
 int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_is_lds);
 
 /* Tuning / test switches: "force_generic" (1: always run the table-free sweep kernel),
- * "max_table_cells" (geometry-table budget in cells; larger problems use the table-free kernel). */
+ * "max_table_cells" (geometry-table budget in cells; larger problems use the table-free kernel),
+ * "lds_stage_limit" (bytes of LDS per workgroup above which the staged column densities live in global
+ * memory; 0 = automatic: half a CU's LDS), "lds_pad" (extra LDS per workgroup, occupancy experiments). */
 int asora_set_option(const char *name, long long value);
 
 /* 1 if the last sweep ran the table-driven kernel, 0 for the table-free one. */
