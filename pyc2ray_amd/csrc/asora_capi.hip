@@ -69,6 +69,7 @@ struct State {
     bool geo_valid = false;
     int lds_stage_limit = 0;      // option "lds_stage_limit": larger staging arrays go to global memory (0: automatic)
     int lds_pad = 0;              // option "lds_pad": extra dynamic LDS per workgroup (occupancy experiments)
+    int wg_threads = 0;           // option "wg_threads": workgroup size of the table-driven kernel, 256/512/1024 (0: automatic)
     int force_generic = 0;        // option "force_generic": always use the table-free kernel
     long long max_table_cells = 48LL << 20;  // option "max_table_cells": beyond this the generic kernel runs
     int last_tab = 0;
@@ -265,12 +266,12 @@ int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
     return 0;
 }
 
-template <bool L, bool H>
+template <bool L, bool H, int T>
 int launch_sweep_tab(const asora::SweepArgs &A, int grid, size_t lds, hipStream_t st) {
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)asora::sweep_tab_kernel<L, H>,
+        HIP_TRY(hipFuncSetAttribute((const void *)asora::sweep_tab_kernel<L, H, T>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((asora::sweep_tab_kernel<L, H>), dim3(grid), dim3(asora::SWEEP_THREADS), lds, st, A);
+    hipLaunchKernelGGL((asora::sweep_tab_kernel<L, H, T>), dim3(grid), dim3(T), lds, st, A);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -376,7 +377,26 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     // 63 KB: LDS 9.4e10 vs global 7.4e10 updates/s; R = 100, 94 KB: LDS 5.9e10 vs global 7.3e10)
     const int lds_limit = S.lds_stage_limit > 0 ? std::min(S.max_lds, S.lds_stage_limit)
                                                 : std::max(S.max_lds / 2, std::min(S.max_lds, 65536));
-    const bool use_lds = lds_stage + lds_fixed + (size_t)S.lds_pad <= (size_t)lds_limit;
+    bool use_lds = lds_stage + lds_fixed + (size_t)S.lds_pad <= (size_t)lds_limit;
+    // Larger workgroups keep 16 waves on a CU with fewer, larger LDS allocations: 512 threads x 2 up to ~80 KB,
+    // ONE 1024-thread workgroup up to the whole LDS.  They pay only once 256 threads would leave the CU
+    // short of waves (measured at 256^3, 1000 sources: R = 60 256 thr 1.21e11, 1024 thr 6.8e10 updates/s;
+    // R = 100: global staging 7.3e10, 1024 thr 1.12e11; R = 120: 7.2e10 vs 1.15e11).
+    int threads = asora::SWEEP_THREADS;
+    if (use_tab) {
+        const size_t full = lds_stage + lds_fixed + (size_t)S.lds_pad;
+        if (S.wg_threads == 256 || S.wg_threads == 512 || S.wg_threads == 1024) {
+            threads = S.wg_threads;
+            if (threads > 256) {
+                if (full > (size_t)S.max_lds) return fail(13, "asora_do_all_sources: wg_threads=%d needs %zu B of LDS", threads, full);
+                use_lds = true;
+            }
+        } else if (S.lds_stage_limit <= 0 && full <= (size_t)S.max_lds) {
+            if (full > (size_t)S.max_lds / 2) threads = 1024;
+            else if (full > (size_t)S.max_lds / 3) threads = 512;
+            if (threads > 256) use_lds = true;
+        }
+    }
     const size_t lds = (use_lds ? lds_stage : 0) + lds_fixed + (size_t)S.lds_pad;
     if (lds > (size_t)S.max_lds) return fail(13, "asora_do_all_sources: per-row tables (%zu B) exceed LDS", lds);
 
@@ -400,8 +420,11 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         S.last_tab = use_tab ? 1 : 0;
         HIP_TRY(hipEventRecord(S.ev0, st));
         if (use_tab) {
-            if (use_lds) rc = want_heat ? launch_sweep_tab<true, true>(A, grid, lds, st) : launch_sweep_tab<true, false>(A, grid, lds, st);
-            else rc = want_heat ? launch_sweep_tab<false, true>(A, grid, lds, st) : launch_sweep_tab<false, false>(A, grid, lds, st);
+            constexpr int T = asora::SWEEP_THREADS;
+            if (threads == 1024) rc = want_heat ? launch_sweep_tab<true, true, 1024>(A, grid, lds, st) : launch_sweep_tab<true, false, 1024>(A, grid, lds, st);
+            else if (threads == 512) rc = want_heat ? launch_sweep_tab<true, true, 512>(A, grid, lds, st) : launch_sweep_tab<true, false, 512>(A, grid, lds, st);
+            else if (use_lds) rc = want_heat ? launch_sweep_tab<true, true, T>(A, grid, lds, st) : launch_sweep_tab<true, false, T>(A, grid, lds, st);
+            else rc = want_heat ? launch_sweep_tab<false, true, T>(A, grid, lds, st) : launch_sweep_tab<false, false, T>(A, grid, lds, st);
         } else {
             if (use_lds) rc = want_heat ? launch_sweep<true, true>(A, grid, lds, st) : launch_sweep<true, false>(A, grid, lds, st);
             else rc = want_heat ? launch_sweep<false, true>(A, grid, lds, st) : launch_sweep<false, false>(A, grid, lds, st);
@@ -409,7 +432,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         if (rc) return rc;
         HIP_TRY(hipEventRecord(S.ev1, st));
         S.timed = true;
-        S.last_grid = grid; S.last_block = asora::SWEEP_THREADS; S.last_lds = (int)lds;
+        S.last_grid = grid; S.last_block = use_tab ? threads : asora::SWEEP_THREADS; S.last_lds = (int)lds;
         S.last_is_lds = use_lds ? 1 : 0;
     }
 
@@ -514,7 +537,7 @@ int asora_device_close(void) {
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     State fresh;  // options and the last launch record survive a close
-    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.max_table_cells = S.max_table_cells;
+    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.max_table_cells = S.max_table_cells;
     fresh.last_tab = S.last_tab; fresh.last_grid = S.last_grid; fresh.last_block = S.last_block;
     fresh.last_lds = S.last_lds; fresh.last_is_lds = S.last_is_lds;
     S = fresh;
@@ -764,6 +787,7 @@ int asora_set_option(const char *name, long long value) {
     else if (!std::strcmp(name, "max_table_cells")) S.max_table_cells = value;
     else if (!std::strcmp(name, "lds_pad")) S.lds_pad = (int)value;
     else if (!std::strcmp(name, "lds_stage_limit")) S.lds_stage_limit = (int)value;
+    else if (!std::strcmp(name, "wg_threads")) S.wg_threads = (int)value;
     else return fail(12, "asora_set_option: unknown option '%s'", name);
     return 0;
 }

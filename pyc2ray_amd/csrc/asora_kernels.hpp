@@ -598,10 +598,12 @@ __device__ __forceinline__ void phase_barrier() {
 #endif
 }
 
-template <bool LDS_STAGE, bool HEAT>
-__global__ __launch_bounds__(SWEEP_THREADS) __attribute__((amdgpu_waves_per_eu(ASORA_WAVES_PER_EU, ASORA_WAVES_PER_EU)))
+// THREADS: 256 (one wave per SIMD and workgroup, 4 workgroups per CU) or 1024 (ONE workgroup per CU that may use the
+// whole LDS: same 16 waves per CU, staging arrays up to ~150 KB)
+template <bool LDS_STAGE, bool HEAT, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(ASORA_WAVES_PER_EU, ASORA_WAVES_PER_EU)))
 void sweep_tab_kernel(SweepArgs A) {
-    constexpr int P = ASORA_PHASE_CHUNKS, NW = SWEEP_THREADS / 64;
+    constexpr int P = ASORA_PHASE_CHUNKS, NW = THREADS / 64;
     const double max_coldensh = (double)2e30f;  // raytracing.f90:368
     PlaneCtx<LDS_STAGE> C;
     const int tid = threadIdx.x;
@@ -618,7 +620,7 @@ void sweep_tab_kernel(SweepArgs A) {
     // the variant's plane table: read through LDS so that stepping to the next plane never touches vmcnt
     PlaneInfo *const planes = reinterpret_cast<PlaneInfo *>(asora_smem + off_du + 5 * W + (W & 1));
     C.stg.g = LDS_STAGE ? nullptr : reinterpret_cast<double2 *>(A.gscratch) + (size_t)blockIdx.x * (size_t)E;
-    C.lg = load_log10_table(A.log10_table, off_du + 5 * W + (W & 1) + 2 * A.nplanes, tid, SWEEP_THREADS);
+    C.lg = load_log10_table(A.log10_table, off_du + 5 * W + (W & 1) + 2 * A.nplanes, tid, THREADS);
     const double w_empty = weightf(0.0, A.sig);  // weight of a guard / never-written entry
 
     for (long long task = blockIdx.x; task < A.ntasks; task += gridDim.x) {
@@ -647,7 +649,7 @@ void sweep_tab_kernel(SweepArgs A) {
         const uint32_t strideU = (axis == 2) ? (uint32_t)N : N2;
         const int variant = A.vmap[(((su < 0) ? 2 : 0) + ((sv < 0) ? 1 : 0)) * 2 + (axis != 0 ? 1 : 0)];
         // (the previous task's last barrier guarantees nobody still reads the plane table)
-        for (int i = tid; i < A.nplanes; i += SWEEP_THREADS) planes[i] = A.planes[(size_t)variant * A.nplanes + i];
+        for (int i = tid; i < A.nplanes; i += THREADS) planes[i] = A.planes[(size_t)variant * A.nplanes + i];
         __syncthreads();
         const uint32_t pos00 = planes[0].off;  // staging position of cell (0, 0) in this variant's layout
 
@@ -664,14 +666,14 @@ void sweep_tab_kernel(SweepArgs A) {
         }
 
         // (the previous task's last barrier guarantees nobody still reads the arrays below)
-        for (int i = tid; i < E; i += SWEEP_THREADS) C.stg.st((uint32_t)i, 0.0, w_empty);
-        for (int i = tid; i < W; i += SWEEP_THREADS) {
+        for (int i = tid; i < E; i += THREADS) C.stg.st((uint32_t)i, 0.0, w_empty);
+        for (int i = tid; i < W; i += THREADS) {
             rowU[i] = (int)((uint32_t)wrap(u0 + su * i, N) * strideU);
             colV[i] = wrap(v0 + sv * i, N);
         }
         {
             const double alam = cinterp_alam(1);
-            for (int i = tid; i < 2 * W; i += SWEEP_THREADS) {
+            for (int i = tid; i < 2 * W; i += THREADS) {
                 if (i < W) du_tab[i] = interp_offsets(i, su, u0 + 1, alam);
                 else dv_tab[i - W] = interp_offsets(i - W, sv, v0 + 1, alam);
             }
@@ -822,7 +824,7 @@ void sweep_tab_kernel(SweepArgs A) {
                 if (woff[q] >= 0) C.stg.st((uint32_t)woff[q], cdo[q], wo[q]);
             if (d1.n != n) {  // last phase of this plane: interpolation offsets of the next one
                 const double alam_next = cinterp_alam(n + 1);
-                for (int i = tid; i < 2 * W; i += SWEEP_THREADS) {
+                for (int i = tid; i < 2 * W; i += THREADS) {
                     if (i < W) du_tab[i] = interp_offsets(i, su, u0 + 1, alam_next);
                     else dv_tab[i - W] = interp_offsets(i - W, sv, v0 + 1, alam_next);
                 }

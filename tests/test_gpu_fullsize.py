@@ -46,12 +46,33 @@ def test_bench_config_vs_oracle(asora, port_oracle, density):
     assert m.sum() > 1_000_000 and np.array_equal(cdh[m], o["coldensh_out"][m])
 
 
+def test_bench_R100_wide_workgroups_vs_oracle(asora, port_oracle):
+    """R = 100 at 256^3: ~94 KB of staged entries; the library picks ONE 1024-thread workgroup per CU
+    (staging stays in LDS) instead of global staging."""
+    c = bench_case(4, "clustered", R=100.0)
+    phi, cdh, _ = run_hip(asora, c)
+    info = asora.last_launch_info()
+    assert info["table_driven"] and info["staging"] == "lds" and info["block"] == 1024, info
+    box = int(np.ceil(c["R"]))
+    o = cases.run_oracle(port_oracle, c, heat=False, sens=True, max_subbox=box, subboxsize=box)
+    r = compare(phi, o["phi_ion"], sens=o["phi_sens"])
+    print(f"\n[bench256 R=100 wide] max_rel={r['max_rel']:.3e} n_rel>1e-10={r['n_rel_gt']} n_sens={r['n_sens']} "
+          f"support_equal={r['support_equal']}")
+    assert r["ok"] and r["support_equal"], r
+    m = (cdh != 0) & (o["coldensh_out"] != 0)
+    assert m.sum() > 4_000_000 and np.array_equal(cdh[m], o["coldensh_out"][m])
+
+
 def test_fullbox_256_single_source_global_staging(asora, port_oracle):
     """configs[0]-like: one source, uniform 256^3, R beyond the box -> the staged entries no longer fit
     in LDS and live in global memory (the kernel's other staging path)."""
     N = 256
     c = cases._base(N, 1.0e3, 0.014 * MPC / 128, [[190, 191, 127]], [10.0], xh=np.full((N, N, N), 1.2e-3))
-    phi, cdh, _ = run_hip(asora, c)
+    asora.set_option("wg_threads", 256)
+    try:
+        phi, cdh, _ = run_hip(asora, c)
+    finally:
+        asora.set_option("wg_threads", 0)
     info = asora.last_launch_info()
     assert info["table_driven"] and info["staging"] == "global", info
     o = cases.run_oracle(port_oracle, c, heat=False, sens=True)
