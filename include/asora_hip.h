@@ -135,8 +135,9 @@ int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_i
 /* Tuning / test switches: "force_generic" (1: always run the table-free sweep kernel),
  * "max_table_cells" (geometry-table budget in cells; larger problems use the table-free kernel),
  * "lds_stage_limit" (bytes of LDS per workgroup above which the staged column densities live in global
- * memory; 0 = automatic: half a CU's LDS), "wg_threads" (256/512/1024: workgroup size of the table-driven
- * kernel; 0 = automatic: 512 / 1024 once fewer than three / two 256-thread workgroups fit on a CU),
+ * memory; 0 = automatic: half a CU's LDS), "wg_threads" (64/128/192/256/512/1024: workgroup size of the
+ * table-driven kernel; 0 = automatic: the smallest size that keeps >= 14 waves on a CU given the LDS one
+ * workgroup needs),
  * "lds_pad" (extra LDS per workgroup, occupancy experiments). */
 int asora_set_option(const char *name, long long value);
 

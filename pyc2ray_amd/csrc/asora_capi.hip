@@ -373,28 +373,38 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         lds_stage = 2 * (size_t)A.plane_elems * sizeof(double);  // table-free kernel: two square planes
         lds_fixed = lds_log;
     }
-    // LDS staging pays while at least two workgroups fit on a CU (measured at 256^3, 1000 sources: R = 80,
-    // 63 KB: LDS 9.4e10 vs global 7.4e10 updates/s; R = 100, 94 KB: LDS 5.9e10 vs global 7.3e10)
+    // Where the staged entries live and how large a workgroup is (table-driven kernel): what counts is ~16
+    // waves per CU, in the SMALLEST workgroups that reach it (small planes leave the waves of a large
+    // workgroup idle, and its barriers span more waves) -- 64 threads at R <~ 25 cells, 128 up to ~45, 192/256
+    // up to ~70, 512 x 2 up to 80 KB (R <~ 92), ONE 1024-thread workgroup with the whole LDS up to R ~ 125;
+    // beyond that (or above the "lds_stage_limit" option) the entries live in a global scratch, 256 threads.
+    // Measured at 256^3, 1000 sources, updates/s: R = 20: 64 thr 5.4e10, 256 thr 3.2e10; R = 40: 128 thr 9.4e10,
+    // 256 thr 8.7e10; R = 60: 256 thr 1.21e11, 512 thr 1.0e11; R = 80: 256 thr 9.4e10, 512 thr 1.26e11;
+    // R = 100: 256 thr 5.9e10, global 7.3e10, 1024 thr 1.12e11; R = 120: global 7.2e10, 1024 thr 1.15e11.
     const int lds_limit = S.lds_stage_limit > 0 ? std::min(S.max_lds, S.lds_stage_limit)
                                                 : std::max(S.max_lds / 2, std::min(S.max_lds, 65536));
     bool use_lds = lds_stage + lds_fixed + (size_t)S.lds_pad <= (size_t)lds_limit;
-    // Larger workgroups keep 16 waves on a CU with fewer, larger LDS allocations: 512 threads x 2 up to ~80 KB,
-    // ONE 1024-thread workgroup up to the whole LDS.  They pay only once 256 threads would leave the CU
-    // short of waves (measured at 256^3, 1000 sources: R = 60 256 thr 1.21e11, 1024 thr 6.8e10 updates/s;
-    // R = 100: global staging 7.3e10, 1024 thr 1.12e11; R = 120: 7.2e10 vs 1.15e11).
     int threads = asora::SWEEP_THREADS;
     if (use_tab) {
         const size_t full = lds_stage + lds_fixed + (size_t)S.lds_pad;
-        if (S.wg_threads == 256 || S.wg_threads == 512 || S.wg_threads == 1024) {
+        if (S.wg_threads == 64 || S.wg_threads == 128 || S.wg_threads == 192 || S.wg_threads == 256 ||
+            S.wg_threads == 512 || S.wg_threads == 1024) {
             threads = S.wg_threads;
-            if (threads > 256) {
+            if (threads != 256) {
                 if (full > (size_t)S.max_lds) return fail(13, "asora_do_all_sources: wg_threads=%d needs %zu B of LDS", threads, full);
                 use_lds = true;
             }
         } else if (S.lds_stage_limit <= 0 && full <= (size_t)S.max_lds) {
-            if (full > (size_t)S.max_lds / 2) threads = 1024;
-            else if (full > (size_t)S.max_lds / 3) threads = 512;
-            if (threads > 256) use_lds = true;
+            // smallest workgroup that still puts >= 14 of the 16 possible waves on a CU, else the one with the most waves
+            static const int sizes[] = {64, 128, 192, 256, 512, 1024};  // (320: measured 30 % slower than 256 / 512)
+            const int fit = (int)((size_t)S.max_lds / ((full + 1023) & ~(size_t)1023));
+            int best_waves = 0;
+            for (int t : sizes) {
+                const int waves = std::min(fit, 16 / (t / 64)) * (t / 64);
+                if (waves > best_waves) { best_waves = waves; threads = t; }
+                if (waves >= 14) break;
+            }
+            use_lds = true;
         }
     }
     const size_t lds = (use_lds ? lds_stage : 0) + lds_fixed + (size_t)S.lds_pad;
@@ -423,6 +433,9 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             constexpr int T = asora::SWEEP_THREADS;
             if (threads == 1024) rc = want_heat ? launch_sweep_tab<true, true, 1024>(A, grid, lds, st) : launch_sweep_tab<true, false, 1024>(A, grid, lds, st);
             else if (threads == 512) rc = want_heat ? launch_sweep_tab<true, true, 512>(A, grid, lds, st) : launch_sweep_tab<true, false, 512>(A, grid, lds, st);
+            else if (threads == 192) rc = want_heat ? launch_sweep_tab<true, true, 192>(A, grid, lds, st) : launch_sweep_tab<true, false, 192>(A, grid, lds, st);
+            else if (threads == 128) rc = want_heat ? launch_sweep_tab<true, true, 128>(A, grid, lds, st) : launch_sweep_tab<true, false, 128>(A, grid, lds, st);
+            else if (threads == 64) rc = want_heat ? launch_sweep_tab<true, true, 64>(A, grid, lds, st) : launch_sweep_tab<true, false, 64>(A, grid, lds, st);
             else if (use_lds) rc = want_heat ? launch_sweep_tab<true, true, T>(A, grid, lds, st) : launch_sweep_tab<true, false, T>(A, grid, lds, st);
             else rc = want_heat ? launch_sweep_tab<false, true, T>(A, grid, lds, st) : launch_sweep_tab<false, false, T>(A, grid, lds, st);
         } else {

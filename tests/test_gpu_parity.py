@@ -176,14 +176,18 @@ def test_table_driven_equals_table_free_kernel(asora, golden_dir, name):
     assert np.array_equal(phi_t, phi_g)
 
 
-@pytest.mark.parametrize("threads", [512, 1024])
+@pytest.mark.parametrize("threads", [64, 128, 192, 512, 1024])
 @pytest.mark.parametrize("name", ["corner32", "lognormal48", "rcut7p3", "thick24"])
-def test_wide_workgroup_equals_256_threads(asora, golden_dir, name, threads):
-    """The 512- and 1024-thread variants (two / one workgroup per CU with half / the whole LDS for the staged
-    entries; picked for radii whose entries leave a CU short of 256-thread workgroups) work a plane off in
-    phases two / four times as large; same arithmetic, so a single source gives bit-identical output."""
+def test_workgroup_sizes_equal_256_threads(asora, golden_dir, name, threads):
+    """The library picks the workgroup size from the size of the staged entries (64 threads at small radii
+    ... ONE 1024-thread workgroup per CU with the whole LDS at R ~ 100-125 cells); the variants differ only
+    in how many 64-cell chunks make a phase, so a single source gives bit-identical output."""
     c = load_golden(golden_dir, name)
-    phi_n, cdh_n, _ = run_hip(asora, c, num_src=1)
+    asora.set_option("wg_threads", 256)
+    try:
+        phi_n, cdh_n, _ = run_hip(asora, c, num_src=1)
+    finally:
+        asora.set_option("wg_threads", 0)
     assert asora.last_launch_info()["block"] == 256
     asora.set_option("wg_threads", threads)
     try:
@@ -195,7 +199,7 @@ def test_wide_workgroup_equals_256_threads(asora, golden_dir, name, threads):
         asora.set_option("wg_threads", 0)
     assert np.array_equal(cdh_w, cdh_n)
     assert np.array_equal(phi_w, phi_n)
-    phi_ref, _, _ = run_hip(asora, c)
+    phi_ref, _, _ = run_hip(asora, c)  # automatic size, all sources
     assert np.allclose(phi_all, phi_ref, rtol=1e-13, atol=0)
 
 
