@@ -125,6 +125,15 @@ int asora_visit_count(double R, int m1, long long *visits, long long *in_sphere)
 int asora_geometry_census(double R, double dr, int m1, long long *owned, long long *owned_rate, long long *computed,
                           int *staging_entries, int *variants);
 
+/* Order in which the library sweeps a source list (pure host function, no device needed): perm[i] = index in
+ * `pos` (x0,y0,z0,x1,... 0-based, as for asora_source_data_to_device) of the i-th source swept.  order 0: as
+ * given, 1: Morton (Z) curve, 2: Hilbert curve (the default, option "source_order").  The rate grids are sums
+ * over sources, so the order only decides which sources are in flight together; neighbours share their
+ * neutral-density reads and meet in cache with their rate atomics.  coldensh_out is that of the caller's last
+ * source whatever the order.  SURVEY.md 8(f)4 (source-list preprocessing); no counterpart in the reference,
+ * which sweeps in list order (src/asora/raytracing.cu:143-158). */
+int asora_source_order(const int32_t *pos, int num_src, int m1, int order, int32_t *perm);
+
 /* Duration of the raytracing sweep kernel of the last do_all_sources* call, from HIP events
  * recorded on the launch stream (synchronises on the stop event). */
 int asora_last_sweep_ms(float *ms);
@@ -138,7 +147,7 @@ int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_i
  * memory; 0 = automatic: half a CU's LDS), "wg_threads" (64/128/192/256/512/1024: workgroup size of the
  * table-driven kernel; 0 = automatic: the smallest size that keeps >= 14 waves on a CU given the LDS one
  * workgroup needs),
- * "lds_pad" (extra LDS per workgroup, occupancy experiments). */
+ * "source_order" (see asora_source_order), "lds_pad" (extra LDS per workgroup, occupancy experiments). */
 int asora_set_option(const char *name, long long value);
 
 /* 1 if the last sweep ran the table-driven kernel, 0 for the table-free one. */

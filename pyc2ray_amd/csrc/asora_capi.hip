@@ -57,9 +57,15 @@ struct State {
     double *thin = nullptr, *thick = nullptr, *hthin = nullptr, *hthick = nullptr;
     int table_len = 0, heat_table_len = 0;
     // sources
-    int *src_pos = nullptr;
+    int *src_pos = nullptr;       // device copies, in SWEEP order (see stage_sources)
     double *src_flux = nullptr;
     int num_src = 0;
+    std::vector<int32_t> host_pos;   // the caller's list, in the caller's order
+    std::vector<double> host_flux;
+    int staged_n = -1;            // the device copies hold the first staged_n sources of the caller's list ...
+    int staged_order = -1;        // ... sorted with this "source_order"
+    int staged_last = -1;         // position of the caller's source staged_n - 1 in the sweep order
+    int source_order = 2;         // option "source_order": 0 as given, 1 Morton, 2 Hilbert curve
     // geometry tables of the table-driven sweep (cached per (N, R, dr))
     asora::PlaneInfo *planes_dev = nullptr;
     uint2 *cell_meta_dev = nullptr;
@@ -286,6 +292,78 @@ int launch_sweep(const asora::SweepArgs &A, int grid, size_t lds, hipStream_t st
     return 0;
 }
 
+// Key of a cell on the 3-D Hilbert curve of 2^bits cells per axis (Skilling's transpose form, AIP Conf. Proc.
+// 707, 381 (2004)): consecutive keys are face neighbours.
+uint64_t hilbert_key(uint32_t x, uint32_t y, uint32_t z, int bits) {
+    uint32_t X[3] = {x, y, z};
+    const uint32_t M = 1u << (bits - 1);
+    for (uint32_t Q = M; Q > 1; Q >>= 1) {
+        const uint32_t P = Q - 1;
+        for (int i = 0; i < 3; i++) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const uint32_t t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    uint32_t t = 0;
+    for (uint32_t Q = M; Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    for (int i = 0; i < 3; i++) X[i] ^= t;
+    uint64_t key = 0;
+    for (int b = bits - 1; b >= 0; b--)
+        for (int i = 0; i < 3; i++) key = (key << 1) | ((X[i] >> b) & 1u);
+    return key;
+}
+uint64_t morton_key(uint32_t x, uint32_t y, uint32_t z, int bits) {
+    uint64_t key = 0;
+    for (int b = bits - 1; b >= 0; b--) key = (key << 3) | (((x >> b) & 1u) << 2) | (((y >> b) & 1u) << 1) | ((z >> b) & 1u);
+    return key;
+}
+
+// The sweep works the source list off in order, ~40 sources in flight at a time on the whole chip, and the rate
+// grid is a SUM over sources: the order is free.  Sorting the list along a space-filling curve makes the
+// sources in flight neighbours, so their neutral-density reads and rate atomics meet in L2 / Infinity Cache
+// (256^3, 1e4 random sources, R = 60: 119.5 -> 105.5 ms).  Done once per uploaded list (and per num_src, since
+// do_all_sources may use a prefix of the list); coldensh_out stays that of the caller's LAST source.
+void sweep_order(const int32_t *pos, int num_src, int N, int order, int *perm) {
+    for (int i = 0; i < num_src; i++) perm[i] = i;
+    if (order == 0 || num_src < 2) return;
+    int bits = 1;
+    while ((1 << bits) < N) bits++;
+    std::vector<uint64_t> key((size_t)num_src);
+    for (int i = 0; i < num_src; i++) {
+        const uint32_t x = (uint32_t)pos[3 * (size_t)i], y = (uint32_t)pos[3 * (size_t)i + 1], z = (uint32_t)pos[3 * (size_t)i + 2];
+        key[i] = order == 1 ? morton_key(x, y, z, bits) : hilbert_key(x, y, z, bits);
+    }
+    std::stable_sort(perm, perm + num_src, [&](int a, int b) { return key[a] < key[b]; });
+}
+
+int stage_sources(int num_src) {
+    if (S.staged_n == num_src && S.staged_order == S.source_order) return 0;
+    std::vector<int> perm((size_t)std::max(num_src, 1));
+    sweep_order(S.host_pos.data(), num_src, S.N, S.source_order, perm.data());
+    std::vector<int32_t> pos(3 * (size_t)num_src);
+    std::vector<double> flux((size_t)num_src);
+    S.staged_last = -1;
+    for (int i = 0; i < num_src; i++) {
+        const size_t j = (size_t)perm[i];
+        pos[3 * (size_t)i] = S.host_pos[3 * j];
+        pos[3 * (size_t)i + 1] = S.host_pos[3 * j + 1];
+        pos[3 * (size_t)i + 2] = S.host_pos[3 * j + 2];
+        flux[i] = S.host_flux[j];
+        if (perm[i] == num_src - 1) S.staged_last = i;
+    }
+    if (num_src > 0) {  // synchronous copies: nothing may still read the previous staging, nothing outlives the vectors
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(S.src_pos, pos.data(), pos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(S.src_flux, flux.data(), flux.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    S.staged_n = num_src;
+    S.staged_order = S.source_order;
+    return 0;
+}
+
 // Common implementation on device pointers.
 int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, const double *xh_dev,
                         double *phi_out_dev, double *heat_out_dev, int num_src, int m1, double minlogtau,
@@ -301,6 +379,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         return fail(7, "asora_do_all_sources_heat: heating tables not uploaded (or shorter than num_tau)");
     if (!(dr > 0.0) || !(R >= 0.0)) return fail(8, "asora_do_all_sources: need dr > 0 and R >= 0");
     if (!xh_dev || !phi_out_dev) return fail(9, "asora_do_all_sources: null xh_av / phi_ion pointer");
+    if (int rc = stage_sources(num_src)) return rc;
 
     const int N = S.N;
     const size_t bytes = S.cells * sizeof(double);
@@ -339,7 +418,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     A.log10_table = S.log10_table;
     A.ntasks = (long long)asora::SECTORS * num_src;
     A.src_begin = 0;
-    A.cdh_src = want_cdh ? num_src - 1 : -1;
+    A.cdh_src = want_cdh ? S.staged_last : -1;
     A.N = N;
     A.q_max = compute_q_max(R, N);
     A.last_r = N / 2 - 1 + N % 2;  // src/asora/raytracing.cu:140-141
@@ -550,7 +629,7 @@ int asora_device_close(void) {
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     State fresh;  // options and the last launch record survive a close
-    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.max_table_cells = S.max_table_cells;
+    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.max_table_cells = S.max_table_cells;
     fresh.last_tab = S.last_tab; fresh.last_grid = S.last_grid; fresh.last_block = S.last_block;
     fresh.last_lds = S.last_lds; fresh.last_is_lds = S.last_is_lds;
     S = fresh;
@@ -592,6 +671,15 @@ int asora_heat_table_to_device(const double *heat_thin_table, const double *heat
     return 0;
 }
 
+int asora_source_order(const int32_t *pos, int num_src, int m1, int order, int32_t *perm) {
+    if (num_src < 0 || m1 < 1 || order < 0 || order > 2 || (num_src > 0 && (!pos || !perm)))
+        return fail(9, "asora_source_order: bad arguments");
+    for (int i = 0; i < 3 * num_src; i++)
+        if (pos[i] < 0 || pos[i] >= m1) return fail(10, "asora_source_order: source %d outside [0, %d)", i / 3, m1);
+    sweep_order(pos, num_src, m1, order, perm);
+    return 0;
+}
+
 int asora_source_data_to_device(const int32_t *pos, const double *flux, int num_src) {
     if (!S.init) return fail(2, "asora_source_data_to_device: device not initialised");
     if (num_src < 0 || (num_src > 0 && (!pos || !flux))) return fail(9, "asora_source_data_to_device: bad arguments");
@@ -608,12 +696,11 @@ int asora_source_data_to_device(const int32_t *pos, const double *flux, int num_
     const size_t n = (size_t)std::max(num_src, 1);
     HIP_TRY(hipMalloc(&S.src_pos, 3 * n * sizeof(int)));
     HIP_TRY(hipMalloc(&S.src_flux, n * sizeof(double)));
-    if (num_src > 0) {
-        HIP_TRY(hipMemcpy(S.src_pos, pos, 3 * (size_t)num_src * sizeof(int), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(S.src_flux, flux, (size_t)num_src * sizeof(double), hipMemcpyHostToDevice));
-    }
+    S.host_pos.assign(pos, pos + 3 * (size_t)num_src);
+    S.host_flux.assign(flux, flux + (size_t)num_src);
+    S.staged_n = -1;
     S.num_src = num_src;
-    return 0;
+    return stage_sources(num_src);  // the usual case: the whole list is raytraced
 }
 
 int asora_do_all_sources(double R, double *coldensh_out, double sig, double dr, const double *ndens,
@@ -801,6 +888,7 @@ int asora_set_option(const char *name, long long value) {
     else if (!std::strcmp(name, "lds_pad")) S.lds_pad = (int)value;
     else if (!std::strcmp(name, "lds_stage_limit")) S.lds_stage_limit = (int)value;
     else if (!std::strcmp(name, "wg_threads")) S.wg_threads = (int)value;
+    else if (!std::strcmp(name, "source_order")) S.source_order = (int)value;
     else return fail(12, "asora_set_option: unknown option '%s'", name);
     return 0;
 }

@@ -50,6 +50,7 @@ ABI = {
     "asora_last_sweep_ms": (C.c_int, [C.POINTER(C.c_float)]),
     "asora_last_launch_info": (C.c_int, [C.POINTER(C.c_int)] * 4),
     "asora_set_option": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "asora_source_order": (C.c_int, [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "asora_last_sweep_is_table_driven": (C.c_int, []),
     "asora_test_division": (C.c_int, [_dp, _dp, C.c_longlong] + [C.POINTER(C.c_longlong)] * 3),
     "asora_last_error": (C.c_char_p, []),
@@ -234,6 +235,16 @@ def geometry_census(R, dr, m1):
     _check(_lib.asora_geometry_census(float(R), float(dr), int(m1), C.byref(a), C.byref(b), C.byref(c), C.byref(e),
                                       C.byref(v)))
     return dict(owned=a.value, owned_rate=b.value, computed=c.value, staging_entries=e.value, variants=v.value)
+
+
+def source_order(pos, N, order=2):
+    """Permutation in which the library sweeps the source list `pos` (flat int32 x0,y0,z0,x1,...)."""
+    pos = np.ascontiguousarray(pos, dtype=np.int32).ravel()
+    n = pos.size // 3
+    perm = np.empty(max(n, 1), dtype=np.int32)
+    _check(_lib.asora_source_order(pos.ctypes.data_as(C.POINTER(C.c_int32)), n, int(N), int(order),
+                                   perm.ctypes.data_as(C.POINTER(C.c_int32))))
+    return perm[:n]
 
 
 def set_option(name, value):

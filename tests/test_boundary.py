@@ -148,3 +148,26 @@ def test_merge_and_bin_sources():
     ii = np.minimum((xyz / 10.0 * 8).astype(int), 7)
     np.add.at(ref, (ii[:, 0], ii[:, 1], ii[:, 2]), m)
     assert np.array_equal(sp, np.argwhere(ref > 0)) and np.allclose(sm, ref[ref > 0], rtol=1e-14)
+
+
+def test_source_sweep_order():
+    """asora_source_order (host only): a permutation; order 0 = as given; the Hilbert order of all cells of a
+    2^k cube is a walk over face neighbours; equal positions keep the caller's order (stable)."""
+    import itertools
+    from pyc2ray_amd import libasora as la
+    rng = np.random.default_rng(3)
+    pos = rng.integers(0, 100, (500, 3)).astype(np.int32)
+    assert np.array_equal(la.source_order(pos.ravel(), 100, 0), np.arange(500))
+    for order in (1, 2):
+        perm = la.source_order(pos.ravel(), 100, order)
+        assert np.array_equal(np.sort(perm), np.arange(500))
+    for N in (8, 16):
+        cells = np.array(list(itertools.product(range(N), repeat=3)), dtype=np.int32)
+        path = cells[la.source_order(cells.ravel(), N, 2)]
+        assert np.all(np.abs(np.diff(path, axis=0)).sum(1) == 1)
+    dup = np.array([[5, 5, 5], [1, 2, 3], [5, 5, 5], [5, 5, 5]], dtype=np.int32)
+    perm = la.source_order(dup.ravel(), 8, 2)
+    assert [int(i) for i in perm if i != 1] == [0, 2, 3]
+    with pytest.raises(RuntimeError):
+        la.source_order(np.array([0, 0, 9], dtype=np.int32), 8, 2)
+    assert la.source_order(np.zeros(0, dtype=np.int32), 8, 2).size == 0

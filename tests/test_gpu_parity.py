@@ -203,6 +203,45 @@ def test_workgroup_sizes_equal_256_threads(asora, golden_dir, name, threads):
     assert np.allclose(phi_all, phi_ref, rtol=1e-13, atol=0)
 
 
+def test_source_order_is_free(asora, golden_dir):
+    """The library sweeps the list along a Hilbert curve (option source_order); phi is a sum over sources, so
+    any order gives the same grid up to the rounding of the sum, and coldensh_out stays that of the caller's
+    LAST source -- also when only a prefix of the uploaded list is raytraced."""
+    c = load_golden(golden_dir, "multi16_unequal")
+    out = {}
+    for order in (0, 1, 2):
+        asora.set_option("source_order", order)
+        try:
+            out[order] = run_hip(asora, c)
+        finally:
+            asora.set_option("source_order", 2)
+    for order in (1, 2):
+        assert np.array_equal(out[order][1], out[0][1])                       # cdh of the last source
+        assert np.allclose(out[order][0], out[0][0], rtol=1e-13, atol=0)
+    # prefix of the uploaded list: same as uploading only the prefix
+    N, ns, k = c["N"], len(c["flux"]), 5
+    asora.device_init(N, 8, 0, 1)
+    try:
+        asora.photo_table_to_device(np.ascontiguousarray(c["thin"]), np.ascontiguousarray(c["thick"]), int(c["num_tau"]))
+        asora.density_to_device(np.ravel(c["ndens"]).astype(np.float64), N)
+        pos = np.ascontiguousarray(np.asarray(c["pos"], dtype=np.int32).reshape(-1, 3).ravel())
+        asora.source_data_to_device(pos, np.ascontiguousarray(c["flux"], dtype=np.float64), ns)
+        xh = np.ravel(c["xh"]).astype(np.float64)
+        res = []
+        for n in (k, ns, k):
+            cdh, phi = np.zeros(N ** 3), np.zeros(N ** 3)
+            asora.do_all_sources(c["R"], cdh, c["sig"], c["dr"], None, xh, phi, n, N, c["minlogtau"], c["dlogtau"],
+                                 int(c["num_tau"]))
+            res.append((phi, cdh))
+    finally:
+        asora.device_close()
+    phi_k, cdh_k, _ = run_hip(asora, c, num_src=k)
+    for i in (0, 2):
+        assert np.array_equal(res[i][1].reshape(N, N, N), cdh_k)
+        assert np.allclose(res[i][0].reshape(N, N, N), phi_k, rtol=1e-13, atol=0)
+    assert np.array_equal(res[1][1].reshape(N, N, N), out[2][1])
+
+
 def test_error_reporting(asora):
     """Errors surface as RuntimeError instead of being swallowed."""
     with pytest.raises(RuntimeError):
