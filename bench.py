@@ -192,6 +192,9 @@ def main():
 
     visits, _ = asora.visit_count(a.R, N)
     in_sphere = asora.geometry_census(a.R, a.dr, N)["owned_rate"]  # the oracle's floating-point sphere test
+    rate_only = "skip_unobserved=1" in os.environ.get("ASORA_OPTIONS", "")
+    if rate_only:  # experiment only: the cells outside the R-sphere are not swept, so they are not counted either
+        visits = in_sphere
     total_visits = float(visits) * a.sources
     value = total_visits * a.steps / dt
     k_ms = float(np.mean(kern_ms))
@@ -217,7 +220,8 @@ def main():
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"raytracing_benchmark: {N}^3 {a.density} grid, {a.sources} sources, "
-                                   f"R_max={a.R:g} cells, cell {a.dr:.4e} cm, xHII {a.xh:g}, NumTau {a.numtau}",
+                                   f"R_max={a.R:g} cells, cell {a.dr:.4e} cm, xHII {a.xh:g}, NumTau {a.numtau}"
+                                   + (" [skip_unobserved: rate-producing cells only]" if rate_only else ""),
                        "visits_per_source": visits, "rate_visits_per_source": in_sphere,
                        "sources_per_gpu": ns_local, "parallelism": f"source-shard x{world} + all-reduce(phi_ion)",
                        "ns_per_source_per_sphere_cell": dt / a.steps / a.sources / (4.0 / 3.0 * np.pi * a.R ** 3) * 1e9,

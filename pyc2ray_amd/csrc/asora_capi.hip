@@ -70,12 +70,13 @@ struct State {
     asora::PlaneInfo *planes_dev = nullptr;
     uint2 *cell_meta_dev = nullptr;
     double2 *cell_geo_dev = nullptr;
-    int geo_N = 0, geo_nplanes = 0, geo_entries = 0, geo_vmap[8] = {0};
+    int geo_N = 0, geo_nplanes = 0, geo_entries = 0, geo_vmap[8] = {0}, geo_nmax_rate = 0;
     double geo_R = -1.0, geo_dr = -1.0;
     bool geo_valid = false;
     int lds_stage_limit = 0;      // option "lds_stage_limit": larger staging arrays go to global memory (0: automatic)
     int lds_pad = 0;              // option "lds_pad": extra dynamic LDS per workgroup (occupancy experiments)
     int wg_threads = 0;           // option "wg_threads": workgroup size of the table-driven kernel, 256/512/1024 (0: automatic)
+    int skip_unobserved = 0;      // option "skip_unobserved": cells outside the R-sphere only for the exported column density
     int force_generic = 0;        // option "force_generic": always use the table-free kernel
     long long max_table_cells = 48LL << 20;  // option "max_table_cells": beyond this the generic kernel runs
     int last_tab = 0;
@@ -268,6 +269,9 @@ int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
     HIP_TRY(hipMemcpy(S.cell_meta_dev, G.meta.data(), G.meta.size() * sizeof(uint2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(S.cell_geo_dev, G.geo.data(), G.geo.size() * sizeof(double2), hipMemcpyHostToDevice));
     for (int i = 0; i < 8; i++) S.geo_vmap[i] = G.vmap[i];
+    S.geo_nmax_rate = 0;
+    for (size_t i = 0; i < G.planes.size(); i++)
+        if (G.planes[i].cntA > 0) S.geo_nmax_rate = std::max(S.geo_nmax_rate, (int)(i % (size_t)G.nplanes));
     S.geo_N = N; S.geo_R = R; S.geo_dr = dr; S.geo_nplanes = G.nplanes; S.geo_entries = G.entries_max; S.geo_valid = true;
     return 0;
 }
@@ -445,6 +449,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         // ONE packed array of (column density, weight) pairs, updated in place, + per-row/column tables
         A.planes = S.planes_dev; A.cell_meta = S.cell_meta_dev; A.cell_geo = S.cell_geo_dev;
         A.nplanes = S.geo_nplanes; A.cw_entries = S.geo_entries;
+        A.rate_only = S.skip_unobserved ? 1 : 0; A.nmax_rate = S.geo_nmax_rate;
         for (int i = 0; i < 8; i++) A.vmap[i] = S.geo_vmap[i];
         lds_stage = (size_t)A.cw_entries * 2 * sizeof(double);
         lds_fixed = (size_t)(5 * A.wtab + (A.wtab & 1) + 2 * A.nplanes) * sizeof(double) + lds_log;
@@ -629,7 +634,7 @@ int asora_device_close(void) {
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     State fresh;  // options and the last launch record survive a close
-    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.max_table_cells = S.max_table_cells;
+    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.max_table_cells = S.max_table_cells;
     fresh.last_tab = S.last_tab; fresh.last_grid = S.last_grid; fresh.last_block = S.last_block;
     fresh.last_lds = S.last_lds; fresh.last_is_lds = S.last_is_lds;
     S = fresh;
@@ -889,6 +894,7 @@ int asora_set_option(const char *name, long long value) {
     else if (!std::strcmp(name, "lds_stage_limit")) S.lds_stage_limit = (int)value;
     else if (!std::strcmp(name, "wg_threads")) S.wg_threads = (int)value;
     else if (!std::strcmp(name, "source_order")) S.source_order = (int)value;
+    else if (!std::strcmp(name, "skip_unobserved")) S.skip_unobserved = value != 0;
     else return fail(12, "asora_set_option: unknown option '%s'", name);
     return 0;
 }

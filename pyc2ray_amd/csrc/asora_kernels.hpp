@@ -89,6 +89,8 @@ struct SweepArgs {
     int cw_entries;            // staged (column density, weight) pairs per task (max over variants)
     int wtab;                  // rows/columns per plane (max) = entries of the per-row / per-column LDS tables
     int vmap[8];               // ((u_is_neg*2 + v_is_neg)*2 + (axis != 0)) -> variant
+    int rate_only;             // option "skip_unobserved": sources other than cdh_src sweep list A only
+    int nmax_rate;             // last plane with a cell inside the R-sphere
 };
 
 // ------------------------------------------------------------------------------------------
@@ -542,25 +544,25 @@ struct PhaseDesc {
     int cntA, cntT, nchunkA, nchunkB;
     bool valid;
 };
-__device__ __forceinline__ void phase_load_plane(PhaseDesc &d, const PlaneInfo *planes, int nmax) {
+__device__ __forceinline__ void phase_load_plane(PhaseDesc &d, const PlaneInfo *planes, int nmax, bool rate_only) {
     d.valid = d.n <= nmax;
     if (d.valid) {
         const PlaneInfo pi = planes[d.n];
         d.off = pi.off;
         d.cntA = (int)pi.cntA;
-        d.cntT = (int)pi.cntT;
+        d.cntT = rate_only ? (int)pi.cntA : (int)pi.cntT;
         d.nchunkA = (d.cntA + 63) >> 6;
         d.nchunkB = (d.cntT - d.cntA + 63) >> 6;
     }
 }
 template <int STEP>
-__device__ __forceinline__ PhaseDesc phase_next(PhaseDesc d, const PlaneInfo *planes, int nmax) {
+__device__ __forceinline__ PhaseDesc phase_next(PhaseDesc d, const PlaneInfo *planes, int nmax, bool rate_only) {
     if (!d.valid) return d;
     d.jbase += STEP;
     if (d.jbase >= d.nchunkA + d.nchunkB) {
         d.n++;
         d.jbase = 0;
-        phase_load_plane(d, planes, nmax);
+        phase_load_plane(d, planes, nmax, rate_only);
     }
     return d;
 }
@@ -644,7 +646,10 @@ void sweep_tab_kernel(SweepArgs A) {
         // ownership: reference tie order (z, y, x) and sign(0) = +1
         const uint32_t ghostmask = (su < 0 ? FLAG_A0 : 0u) | (sv < 0 ? FLAG_B0 : 0u) | (axis >= 1 ? FLAG_BN : 0u) |
                                    (axis == 2 ? FLAG_AN : 0u);
-        const int nmax = min(sp > 0 ? A.last_r : A.last_l, A.q_max);
+        // Cells outside the R-sphere (list B) are never upwind of a cell inside it: they only feed the exported
+        // column density.  With "skip_unobserved" every other source sweeps list A only.
+        const bool rate_only = A.rate_only && src != A.cdh_src;
+        const int nmax = min(min(sp > 0 ? A.last_r : A.last_l, A.q_max), rate_only ? A.nmax_rate : 0x7fffffff);
         const uint32_t strideP = (axis == 2) ? N2 : (uint32_t)N;
         const uint32_t strideU = (axis == 2) ? (uint32_t)N : N2;
         const int variant = A.vmap[(((su < 0) ? 2 : 0) + ((sv < 0) ? 1 : 0)) * 2 + (axis != 0 ? 1 : 0)];
@@ -656,8 +661,8 @@ void sweep_tab_kernel(SweepArgs A) {
         // phase descriptors of p and p+1, cell coordinates of p
         PhaseDesc d0, d1;
         d0.n = 1; d0.jbase = 0; d0.off = 0; d0.cntA = d0.cntT = d0.nchunkA = d0.nchunkB = 0;
-        phase_load_plane(d0, planes, nmax);
-        d1 = phase_next<NW * P>(d0, planes, nmax);
+        phase_load_plane(d0, planes, nmax, rate_only);
+        d1 = phase_next<NW * P>(d0, planes, nmax, rate_only);
         uint2 meta_c[P], meta_n[P];
 #pragma unroll
         for (int q = 0; q < P; q++) {
@@ -832,7 +837,7 @@ void sweep_tab_kernel(SweepArgs A) {
             phase_barrier<LDS_STAGE>();  // new values visible
             // ---- rotate the pipeline --------------------------------------------------------------
             d0 = d1;
-            d1 = phase_next<NW * P>(d1, planes, nmax);
+            d1 = phase_next<NW * P>(d1, planes, nmax, rate_only);
 #pragma unroll
             for (int q = 0; q < P; q++) {
                 meta_c[q] = meta_n[q];

@@ -66,13 +66,16 @@ def test_global_pass_dev_stats(asora, port_oracle):
     assert abs(s0 - (1.0 - xi).sum()) <= 1e-9 * (1.0 - xi).sum()
 
 
-def test_evolve_step_vs_golden(golden_dir):
-    """One full evolve step through pyc2ray_amd.evolve.evolve3D (device-resident loop)."""
+@pytest.mark.parametrize("skip_unobserved", [0, 1])
+def test_evolve_step_vs_golden(golden_dir, skip_unobserved):
+    """One full evolve step through pyc2ray_amd.evolve.evolve3D (device-resident loop); also with the
+    skip_unobserved option (cells outside the R-sphere swept for the last source only)."""
     from pyc2ray_amd import asora_core
     from pyc2ray_amd.evolve import evolve3D
     g = np.load(os.path.join(golden_dir, "evolve32.npz"))
     c = cases.evolve_case()
     N = c["N"]
+    asora_core.libasora.set_option("skip_unobserved", skip_unobserved)
     asora_core.device_init(N, 8, 0, 1)
     try:
         asora_core.photo_table_to_device(c["thin"], c["thick"])
@@ -83,6 +86,7 @@ def test_evolve_step_vs_golden(golden_dir):
                                     *[c[k] for k in CHEM_KEYS], history=hist)
     finally:
         asora_core.device_close()
+        asora_core.libasora.set_option("skip_unobserved", 0)
     err = np.max(np.abs(xh_new - g["xh_new"]))
     m = g["phi_ion"] > 0
     rel_phi = np.max(np.abs(phi[m] / g["phi_ion"][m] - 1.0))

@@ -242,6 +242,23 @@ def test_source_order_is_free(asora, golden_dir):
     assert np.array_equal(res[1][1].reshape(N, N, N), out[2][1])
 
 
+@pytest.mark.parametrize("name", ["multi16_unequal", "rcut7p3", "lognormal48", "corner33"])
+def test_skip_unobserved_cells(asora, golden_dir, name):
+    """Option skip_unobserved (off by default; never used by bench.py): cells outside the R-sphere are not
+    upwind of any cell inside it, so they only matter for the exported column density (the last source's).
+    With the option every other source sweeps the rate-producing cells only: same phi, same coldensh_out."""
+    c = load_golden(golden_dir, name)
+    phi0, cdh0, _ = run_hip(asora, c)
+    asora.set_option("skip_unobserved", 1)
+    try:
+        phi1, cdh1, _ = run_hip(asora, c)
+    finally:
+        asora.set_option("skip_unobserved", 0)
+    assert np.array_equal(cdh1, cdh0)
+    assert np.array_equal(phi1 != 0, phi0 != 0)
+    assert np.allclose(phi1, phi0, rtol=1e-13, atol=0)
+
+
 def test_error_reporting(asora):
     """Errors surface as RuntimeError instead of being swallowed."""
     with pytest.raises(RuntimeError):
