@@ -497,6 +497,28 @@ __device__ __forceinline__ T *ptr_byte(T *base, uint32_t byte_off) {
     return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off);
 }
 
+// Rate accumulation through BUFFER atomics: a lane that has nothing to add gets an offset beyond the
+// descriptor's range and the hardware drops it -- no branch around the instruction.  That matters because the
+// memory counter retires in issue order and the compiler must assume the SHORTEST path when it counts how
+// many younger operations may stay in flight: with a conditional atomic every wait for a load issued
+// before the atomics (the next phase's geometry / neutral density) also waited for the atomics themselves
+// (memory-side, ~2 us).  Issued unconditionally they are counted exactly and complete behind the next
+// phase's interpolation.  (The intrinsic is the one the backend selects buffer_atomic_add_f64 from; clang has
+// no builtin for the f64 form.)
+typedef int rsrc_t __attribute__((ext_vector_type(4)));
+__device__ double llvm_amdgcn_raw_buffer_atomic_fadd_f64(double vdata, rsrc_t rsrc, int voffset, int soffset,
+                                                         int aux) __asm("llvm.amdgcn.raw.buffer.atomic.fadd.f64");
+constexpr uint32_t BUFFER_OOB = 0x80000000u;  // >= num_records of every grid the table-driven kernel accepts
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    rsrc_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));  // stride 0: raw buffer
+    r.z = (int)bytes;
+    r.w = 0x00020000;  // gfx9 raw-buffer word 3 (32-bit data format), no swizzle
+    return r;
+}
+
 // cell_meta.x
 constexpr uint32_t META_COORD_BITS = 10, META_COORD_MASK = (1u << META_COORD_BITS) - 1;
 constexpr uint32_t META_FLAG_SHIFT = 2 * META_COORD_BITS;
@@ -643,6 +665,8 @@ void sweep_tab_kernel(SweepArgs A) {
         double *__restrict__ phi = (axis == 0) ? A.phiB : A.phiA;
         double *__restrict__ heat = (axis == 0) ? A.heatB : A.heatA;
         double *__restrict__ cdh = (src == A.cdh_src) ? ((axis == 0) ? A.cdhB : A.cdhA) : nullptr;
+        const rsrc_t phi_rs = make_rsrc(phi, N2 * (uint32_t)N * 8u);
+        const rsrc_t heat_rs = make_rsrc(HEAT ? heat : phi, N2 * (uint32_t)N * 8u);
         // ownership: reference tie order (z, y, x) and sign(0) = +1
         const uint32_t ghostmask = (su < 0 ? FLAG_A0 : 0u) | (sv < 0 ? FLAG_B0 : 0u) | (axis >= 1 ? FLAG_BN : 0u) |
                                    (axis == 2 ? FLAG_AN : 0u);
@@ -721,14 +745,14 @@ void sweep_tab_kernel(SweepArgs A) {
 
         while (d0.valid) {
             // ---- cell coordinates of the next phase: in flight during this phase's interpolation ------
+            // (unconditional -- past the last phase slot_index gives cell 0 of the last plane -- so that the
+            // compiler counts the operations in flight exactly, see make_rsrc)
             uint32_t idx_n[P];
-            if (d1.valid) {
 #pragma unroll
-                for (int q = 0; q < P; q++) {
-                    bool v, ia;
-                    idx_n[q] = d1.off + slot_index<NW>(d1, wave, q, lane, v, ia);
-                    meta_n[q] = at_byte(A.cell_meta, idx_n[q] * 8u);
-                }
+            for (int q = 0; q < P; q++) {
+                bool v, ia;
+                idx_n[q] = d1.off + slot_index<NW>(d1, wave, q, lane, v, ia);
+                meta_n[q] = at_byte(A.cell_meta, idx_n[q] * 8u);
             }
 
             // ---- phase p: interpolation and rates from the old staged values ---------------------
@@ -789,8 +813,8 @@ void sweep_tab_kernel(SweepArgs A) {
                 }
             }
             // ---- geometry + neutral density of the next phase: in flight during this phase's rates ------
-            if (d1.valid) {
-                const uint32_t baseP = (uint32_t)wrap(p0 + sp * d1.n, N) * strideP;
+            {
+                const uint32_t baseP = (uint32_t)wrap(p0 + sp * min(d1.n, nmax), N) * strideP;
 #pragma unroll
                 for (int q = 0; q < P; q++) {
                     const uint32_t a = meta_n[q].x & META_COORD_MASK, b = (meta_n[q].x >> META_COORD_BITS) & META_COORD_MASK;
@@ -815,13 +839,13 @@ void sweep_tab_kernel(SweepArgs A) {
 #pragma unroll
             for (int q = 0; q < P; q++) {
 #ifdef ASORA_ABL_NOATOMIC
-                if (fire[q] && ph[q] == 1.2345e300) {  // ablation build: rates computed, (almost) never added
+                const bool add = fire[q] && ph[q] == 1.2345e300;  // ablation build: rates computed, (almost) never added
 #else
-                if (fire[q]) {
+                const bool add = fire[q];
 #endif
-                    unsafeAtomicAdd(ptr_byte(phi, g_c[q] * 8u), ph[q]);
-                    if (HEAT) unsafeAtomicAdd(ptr_byte(heat, g_c[q] * 8u), ht[q]);
-                }
+                const int off = (int)(add ? g_c[q] * 8u : BUFFER_OOB);
+                (void)llvm_amdgcn_raw_buffer_atomic_fadd_f64(ph[q], phi_rs, off, 0, 0);
+                if (HEAT) (void)llvm_amdgcn_raw_buffer_atomic_fadd_f64(ht[q], heat_rs, off, 0, 0);
             }
             phase_barrier<LDS_STAGE>();  // every wave has read the old values it needs
 #pragma unroll

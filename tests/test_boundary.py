@@ -171,3 +171,27 @@ def test_source_sweep_order():
     with pytest.raises(RuntimeError):
         la.source_order(np.array([0, 0, 9], dtype=np.int32), 8, 2)
     assert la.source_order(np.zeros(0, dtype=np.int32), 8, 2).size == 0
+
+
+def test_cbin_round_trip(tmp_path):
+    """C2Ray binary grids (pyc2ray_amd/cbin.py): int32[3] header + flat array, Fortran order for the files the
+    reference's write_output produces."""
+    import struct
+    from pyc2ray_amd.cbin import read_cbin, save_cbin, write_output
+    rng = np.random.default_rng(0)
+    a = rng.random((3, 4, 5))
+    f = str(tmp_path / "x.dat")
+    save_cbin(f, a, bits=64, order="F")
+    raw = open(f, "rb").read()
+    assert len(raw) == 12 + 8 * a.size
+    assert struct.unpack("<3i", raw[:12]) == (3, 4, 5)
+    assert struct.unpack("<d", raw[12:20])[0] == a[0, 0, 0] and struct.unpack("<d", raw[20:28])[0] == a[1, 0, 0]
+    assert np.array_equal(read_cbin(f, bits=64, order="F"), a)
+    save_cbin(f, a, bits=32, order="C")
+    b = read_cbin(f, bits=32, order="C")
+    assert b.dtype == np.float32 and np.array_equal(b, a.astype(np.float32))
+    write_output(str(tmp_path / "run_"), 7.0591, a, 2 * a)
+    assert np.array_equal(read_cbin(str(tmp_path / "run_xfrac_z7.059.dat"), bits=64, order="F"), a)
+    assert np.array_equal(read_cbin(str(tmp_path / "run_IonRates_z7.059.dat"), bits=32, order="F"), (2 * a).astype(np.float32))
+    with pytest.raises(ValueError):
+        read_cbin(f, bits=64, order="C")  # wrong width: fewer values than the header promises
