@@ -212,6 +212,20 @@ def main():
             traffic = None
     checksum = float(phi_t.sum().item())
     asora.device_close()
+    # second denominator: what a plain device-to-device copy achieves on this box
+    copy_gbs = None
+    if rank == 0:
+        src_t = torch.empty(1 << 27, dtype=torch.float64, device=dev)  # 1 GiB
+        dst_t = torch.empty_like(src_t)
+        dst_t.copy_(src_t)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst_t.copy_(src_t)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2.0 * src_t.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src_t, dst_t
 
     if rank == 0:
         line = {
@@ -227,7 +241,8 @@ def main():
                        "ns_per_source_per_sphere_cell": dt / a.steps / a.sources / (4.0 / 3.0 * np.pi * a.R ** 3) * 1e9,
                        "phi_checksum": checksum},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "asora::sweep_tab_kernel" if info["table_driven"] else "asora::sweep_kernel",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None, "kernel": "asora::sweep_tab_kernel" if info["table_driven"] else "asora::sweep_kernel",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes,
                          "launch": info},
         }
