@@ -147,6 +147,8 @@ int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_i
  * memory; 0 = automatic: half a CU's LDS), "wg_threads" (64/128/192/256/512/1024: workgroup size of the
  * table-driven kernel; 0 = automatic: the smallest size that keeps >= 14 waves on a CU given the LDS one
  * workgroup needs),
+ * "compact_staging" (1: stage column densities only and recompute the weights, 8 instead of 16 B
+ * of LDS per entry; 0 = automatic: when the pairs would allow at most one workgroup per CU; -1: never),
  * "source_order" (see asora_source_order),
  * "skip_unobserved" (1: cells outside the R-sphere -- never upwind of a cell inside it -- are swept only for
  * the source whose column density is exported; phi and coldensh_out unchanged, ~27 % less time at 256^3 / R = 60;

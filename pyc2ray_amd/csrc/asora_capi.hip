@@ -76,6 +76,7 @@ struct State {
     int lds_stage_limit = 0;      // option "lds_stage_limit": larger staging arrays go to global memory (0: automatic)
     int lds_pad = 0;              // option "lds_pad": extra dynamic LDS per workgroup (occupancy experiments)
     int wg_threads = 0;           // option "wg_threads": workgroup size of the table-driven kernel, 256/512/1024 (0: automatic)
+    int compact_staging = 0;      // option "compact_staging": stage column densities only (0: automatic, 1: always, -1: never)
     int skip_unobserved = 0;      // option "skip_unobserved": cells outside the R-sphere only for the exported column density
     int force_generic = 0;        // option "force_generic": always use the table-free kernel
     long long max_table_cells = 48LL << 20;  // option "max_table_cells": beyond this the generic kernel runs
@@ -276,12 +277,12 @@ int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
     return 0;
 }
 
-template <bool L, bool H, int T>
+template <bool L, bool H, int T, bool WS = true>
 int launch_sweep_tab(const asora::SweepArgs &A, int grid, size_t lds, hipStream_t st) {
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)asora::sweep_tab_kernel<L, H, T>,
+        HIP_TRY(hipFuncSetAttribute((const void *)asora::sweep_tab_kernel<L, H, T, WS>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((asora::sweep_tab_kernel<L, H, T>), dim3(grid), dim3(T), lds, st, A);
+    hipLaunchKernelGGL((asora::sweep_tab_kernel<L, H, T, WS>), dim3(grid), dim3(T), lds, st, A);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -444,7 +445,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         if (int rc2 = build_geometry(N, R, dr, A.q_max, A.last_l, A.last_r, st)) return rc2;
         if (S.geo_entries > 65535) use_tab = false;
     }
-    size_t lds_stage, lds_fixed;
+    size_t lds_stage, lds_stage_c = 0, lds_fixed;
     if (use_tab) {
         // ONE packed array of (column density, weight) pairs, updated in place, + per-row/column tables
         A.planes = S.planes_dev; A.cell_meta = S.cell_meta_dev; A.cell_geo = S.cell_geo_dev;
@@ -452,6 +453,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         A.rate_only = S.skip_unobserved ? 1 : 0; A.nmax_rate = S.geo_nmax_rate;
         for (int i = 0; i < 8; i++) A.vmap[i] = S.geo_vmap[i];
         lds_stage = (size_t)A.cw_entries * 2 * sizeof(double);
+        lds_stage_c = (size_t)((A.cw_entries + 1) & ~1) * sizeof(double);  // column densities only
         lds_fixed = (size_t)(5 * A.wtab + (A.wtab & 1) + 2 * A.nplanes) * sizeof(double) + lds_log;
     } else {
         lds_stage = 2 * (size_t)A.plane_elems * sizeof(double);  // table-free kernel: two square planes
@@ -460,13 +462,26 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     // Where the staged entries live and how large a workgroup is (table-driven kernel): what counts is ~16
     // waves per CU, in the SMALLEST workgroups that reach it (small planes leave the waves of a large
     // workgroup idle, and its barriers span more waves) -- 64 threads at R <~ 25 cells, 128 up to ~45, 192/256
-    // up to ~70, 512 x 2 up to 80 KB (R <~ 92), ONE 1024-thread workgroup with the whole LDS up to R ~ 125;
-    // beyond that (or above the "lds_stage_limit" option) the entries live in a global scratch, 256 threads.
+    // up to ~70, 512 x 2 up to 80 KB (R <~ 92 with pairs, <~ 130 with column densities only), ONE 1024-thread
+    // workgroup with the whole LDS up to R ~ 180; beyond that (or above the "lds_stage_limit" option) the entries
+    // live in a global scratch, 256 threads.
     // Measured at 256^3, 1000 sources, updates/s: R = 20: 64 thr 5.4e10, 256 thr 3.2e10; R = 40: 128 thr 9.4e10,
     // 256 thr 8.7e10; R = 60: 256 thr 1.21e11, 512 thr 1.0e11; R = 80: 256 thr 9.4e10, 512 thr 1.26e11;
     // R = 100: 256 thr 5.9e10, global 7.3e10, 1024 thr 1.12e11; R = 120: global 7.2e10, 1024 thr 1.15e11.
     const int lds_limit = S.lds_stage_limit > 0 ? std::min(S.max_lds, S.lds_stage_limit)
                                                 : std::max(S.max_lds / 2, std::min(S.max_lds, 65536));
+    // Column-density-only staging (8 B per entry, the four weights recomputed per cell: +13 % instructions) once
+    // the (column density, weight) pairs would leave room for ONE workgroup per CU or none: two 512-thread
+    // workgroups beat one of 1024 threads (256^3, 1000 sources: R = 100 1.18e11 -> 1.31e11, R = 128 1.19e11 ->
+    // 1.25e11 updates/s; equal at R = 80), and the LDS range doubles (R = 140: global 7.2e10 -> 1.04e11,
+    // R = 160: 7.0e10 -> 9.9e10; 256^3 full box and 512^3 at R = 150 fit).
+    bool compact = false;
+    if (use_tab && S.lds_stage_limit <= 0 && S.compact_staging >= 0 &&
+        lds_stage_c + lds_fixed + (size_t)S.lds_pad <= (size_t)S.max_lds &&
+        (S.compact_staging > 0 || lds_stage + lds_fixed + (size_t)S.lds_pad > (size_t)S.max_lds / 2)) {
+        compact = true;
+        lds_stage = lds_stage_c;
+    }
     bool use_lds = lds_stage + lds_fixed + (size_t)S.lds_pad <= (size_t)lds_limit;
     int threads = asora::SWEEP_THREADS;
     if (use_tab) {
@@ -474,7 +489,8 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         if (S.wg_threads == 64 || S.wg_threads == 128 || S.wg_threads == 192 || S.wg_threads == 256 ||
             S.wg_threads == 512 || S.wg_threads == 1024) {
             threads = S.wg_threads;
-            if (threads != 256) {
+            if (compact && threads < 256) return fail(13, "asora_do_all_sources: compact staging needs wg_threads >= 256");
+            if (threads != 256 || compact) {
                 if (full > (size_t)S.max_lds) return fail(13, "asora_do_all_sources: wg_threads=%d needs %zu B of LDS", threads, full);
                 use_lds = true;
             }
@@ -484,6 +500,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             const int fit = (int)((size_t)S.max_lds / ((full + 1023) & ~(size_t)1023));
             int best_waves = 0;
             for (int t : sizes) {
+                if (compact && t < 256) continue;
                 const int waves = std::min(fit, 16 / (t / 64)) * (t / 64);
                 if (waves > best_waves) { best_waves = waves; threads = t; }
                 if (waves >= 14) break;
@@ -515,13 +532,20 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         HIP_TRY(hipEventRecord(S.ev0, st));
         if (use_tab) {
             constexpr int T = asora::SWEEP_THREADS;
-            if (threads == 1024) rc = want_heat ? launch_sweep_tab<true, true, 1024>(A, grid, lds, st) : launch_sweep_tab<true, false, 1024>(A, grid, lds, st);
-            else if (threads == 512) rc = want_heat ? launch_sweep_tab<true, true, 512>(A, grid, lds, st) : launch_sweep_tab<true, false, 512>(A, grid, lds, st);
-            else if (threads == 192) rc = want_heat ? launch_sweep_tab<true, true, 192>(A, grid, lds, st) : launch_sweep_tab<true, false, 192>(A, grid, lds, st);
-            else if (threads == 128) rc = want_heat ? launch_sweep_tab<true, true, 128>(A, grid, lds, st) : launch_sweep_tab<true, false, 128>(A, grid, lds, st);
-            else if (threads == 64) rc = want_heat ? launch_sweep_tab<true, true, 64>(A, grid, lds, st) : launch_sweep_tab<true, false, 64>(A, grid, lds, st);
-            else if (use_lds) rc = want_heat ? launch_sweep_tab<true, true, T>(A, grid, lds, st) : launch_sweep_tab<true, false, T>(A, grid, lds, st);
-            else rc = want_heat ? launch_sweep_tab<false, true, T>(A, grid, lds, st) : launch_sweep_tab<false, false, T>(A, grid, lds, st);
+#define ASORA_LAUNCH_TAB(L, TH, WS) \
+    (want_heat ? launch_sweep_tab<L, true, TH, WS>(A, grid, lds, st) : launch_sweep_tab<L, false, TH, WS>(A, grid, lds, st))
+            if (compact) {
+                if (threads == 1024) rc = ASORA_LAUNCH_TAB(true, 1024, false);
+                else if (threads == 512) rc = ASORA_LAUNCH_TAB(true, 512, false);
+                else rc = ASORA_LAUNCH_TAB(true, T, false);
+            } else if (threads == 1024) rc = ASORA_LAUNCH_TAB(true, 1024, true);
+            else if (threads == 512) rc = ASORA_LAUNCH_TAB(true, 512, true);
+            else if (threads == 192) rc = ASORA_LAUNCH_TAB(true, 192, true);
+            else if (threads == 128) rc = ASORA_LAUNCH_TAB(true, 128, true);
+            else if (threads == 64) rc = ASORA_LAUNCH_TAB(true, 64, true);
+            else if (use_lds) rc = ASORA_LAUNCH_TAB(true, T, true);
+            else rc = ASORA_LAUNCH_TAB(false, T, true);
+#undef ASORA_LAUNCH_TAB
         } else {
             if (use_lds) rc = want_heat ? launch_sweep<true, true>(A, grid, lds, st) : launch_sweep<true, false>(A, grid, lds, st);
             else rc = want_heat ? launch_sweep<false, true>(A, grid, lds, st) : launch_sweep<false, false>(A, grid, lds, st);
@@ -530,7 +554,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         HIP_TRY(hipEventRecord(S.ev1, st));
         S.timed = true;
         S.last_grid = grid; S.last_block = use_tab ? threads : asora::SWEEP_THREADS; S.last_lds = (int)lds;
-        S.last_is_lds = use_lds ? 1 : 0;
+        S.last_is_lds = use_lds ? (compact ? 2 : 1) : 0;
     }
 
     hipLaunchKernelGGL(asora::finalize_kernel, tg, tb, 0, st, S.phiA, S.phiB, phi_out_dev, N);
@@ -634,7 +658,7 @@ int asora_device_close(void) {
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     State fresh;  // options and the last launch record survive a close
-    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.max_table_cells = S.max_table_cells;
+    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.compact_staging = S.compact_staging; fresh.max_table_cells = S.max_table_cells;
     fresh.last_tab = S.last_tab; fresh.last_grid = S.last_grid; fresh.last_block = S.last_block;
     fresh.last_lds = S.last_lds; fresh.last_is_lds = S.last_is_lds;
     S = fresh;
@@ -894,6 +918,7 @@ int asora_set_option(const char *name, long long value) {
     else if (!std::strcmp(name, "lds_stage_limit")) S.lds_stage_limit = (int)value;
     else if (!std::strcmp(name, "wg_threads")) S.wg_threads = (int)value;
     else if (!std::strcmp(name, "source_order")) S.source_order = (int)value;
+    else if (!std::strcmp(name, "compact_staging")) S.compact_staging = (int)value;
     else if (!std::strcmp(name, "skip_unobserved")) S.skip_unobserved = value != 0;
     else return fail(12, "asora_set_option: unknown option '%s'", name);
     return 0;

@@ -524,14 +524,28 @@ constexpr uint32_t META_COORD_BITS = 10, META_COORD_MASK = (1u << META_COORD_BIT
 constexpr uint32_t META_FLAG_SHIFT = 2 * META_COORD_BITS;
 enum : uint32_t { FLAG_A0 = 1, FLAG_B0 = 2, FLAG_AN = 4, FLAG_BN = 8 };  // a == 0, b == 0, a == n, b == n
 
-template <bool LDS_STAGE>
+// Staged column densities of one workgroup.  WSTAGED: the weight 1/max(0.6, tau) is staged next to the
+// column density (16 B per entry, computed once per produced cell); otherwise only the column density is
+// staged (8 B per entry: twice the radius range fits in LDS) and the four weights are recomputed per cell.
+template <bool LDS_STAGE, bool WSTAGED>
 struct StageCW {
     double2 *g;  // global staging (when LDS is too small)
+    double sig;
     __device__ __forceinline__ double2 ld(uint32_t p) const {
+        if (!WSTAGED) {
+            double2 v;
+            v.x = asora_smem[p];
+            v.y = weightf(v.x, sig);
+            return v;
+        }
         if (LDS_STAGE) return reinterpret_cast<const double2 *>(asora_smem)[p];
         return g[p];
     }
     __device__ __forceinline__ void st(uint32_t p, double c, double w) const {
+        if (!WSTAGED) {
+            asora_smem[p] = c;
+            return;
+        }
         double2 v;
         v.x = c;
         v.y = w;
@@ -541,9 +555,9 @@ struct StageCW {
 };
 
 // Staging array + log10 table of one workgroup.
-template <bool LDS_STAGE>
+template <bool LDS_STAGE, bool WSTAGED>
 struct PlaneCtx {
-    StageCW<LDS_STAGE> stg;
+    StageCW<LDS_STAGE, WSTAGED> stg;
     Log10LDS lg;
 };
 
@@ -624,19 +638,21 @@ __device__ __forceinline__ void phase_barrier() {
 
 // THREADS: 256 (one wave per SIMD and workgroup, 4 workgroups per CU) or 1024 (ONE workgroup per CU that may use the
 // whole LDS: same 16 waves per CU, staging arrays up to ~150 KB)
-template <bool LDS_STAGE, bool HEAT, int THREADS>
+template <bool LDS_STAGE, bool HEAT, int THREADS, bool WSTAGED>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(ASORA_WAVES_PER_EU, ASORA_WAVES_PER_EU)))
 void sweep_tab_kernel(SweepArgs A) {
     constexpr int P = ASORA_PHASE_CHUNKS, NW = THREADS / 64;
     const double max_coldensh = (double)2e30f;  // raytracing.f90:368
-    PlaneCtx<LDS_STAGE> C;
+    static_assert(LDS_STAGE || WSTAGED, "column-density-only staging is an LDS layout");
+    PlaneCtx<LDS_STAGE, WSTAGED> C;
+    C.stg.sig = A.sig;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int N = A.N;
     const uint32_t N2 = (uint32_t)N * (uint32_t)N;
-    // LDS (in doubles): [cw pairs: 2*E (LDS staging only)] [du: 2W] [dv: 2W] [rowU, colV: W ints each] [log10 table]
+    // LDS (in doubles): [cw pairs: 2*E, or column densities: E rounded up to even (LDS staging only)] [du: 2W] [dv: 2W] [rowU, colV: W ints each] [log10 table]
     const int E = A.cw_entries, W = A.wtab;
-    const int off_du = LDS_STAGE ? 2 * E : 0;
+    const int off_du = LDS_STAGE ? (WSTAGED ? 2 * E : (E + 1) & ~1) : 0;
     double2 *const du_tab = reinterpret_cast<double2 *>(asora_smem + off_du);
     double2 *const dv_tab = du_tab + W;
     int *const rowU = reinterpret_cast<int *>(asora_smem + off_du + 4 * W);
@@ -799,7 +815,7 @@ void sweep_tab_kernel(SweepArgs A) {
                     const double c_out = cdh_in + nhi_c[q] * geo_c[q].x;
                     cin[q] = cdh_in;
                     cdo[q] = c_out;
-                    wo[q] = weightf(c_out, A.sig);
+                    wo[q] = WSTAGED ? weightf(c_out, A.sig) : 0.0;
                     woff[q] = valid ? (int)o_cur + 1 : -1;
                     const bool ghost = ((m.x >> META_FLAG_SHIFT) & ghostmask) != 0;
                     const bool own = valid && !ghost;

@@ -47,12 +47,12 @@ def test_bench_config_vs_oracle(asora, port_oracle, density):
 
 
 def test_bench_R100_wide_workgroups_vs_oracle(asora, port_oracle):
-    """R = 100 at 256^3: ~94 KB of staged entries; the library picks ONE 1024-thread workgroup per CU
-    (staging stays in LDS) instead of global staging."""
+    """R = 100 at 256^3: 94 KB of staged (column density, weight) pairs; the library stages the column
+    densities only (47 KB) and runs two 512-thread workgroups per CU instead of global staging."""
     c = bench_case(4, "clustered", R=100.0)
     phi, cdh, _ = run_hip(asora, c)
     info = asora.last_launch_info()
-    assert info["table_driven"] and info["staging"] == "lds" and info["block"] == 1024, info
+    assert info["table_driven"] and info["staging"] == "lds-compact" and info["block"] == 512, info
     box = int(np.ceil(c["R"]))
     o = cases.run_oracle(port_oracle, c, heat=False, sens=True, max_subbox=box, subboxsize=box)
     r = compare(phi, o["phi_ion"], sens=o["phi_sens"])
@@ -68,13 +68,17 @@ def test_fullbox_256_single_source_global_staging(asora, port_oracle):
     in LDS and live in global memory (the kernel's other staging path)."""
     N = 256
     c = cases._base(N, 1.0e3, 0.014 * MPC / 128, [[190, 191, 127]], [10.0], xh=np.full((N, N, N), 1.2e-3))
-    asora.set_option("wg_threads", 256)
+    asora.set_option("compact_staging", -1)
     try:
         phi, cdh, _ = run_hip(asora, c)
     finally:
-        asora.set_option("wg_threads", 0)
+        asora.set_option("compact_staging", 0)
     info = asora.last_launch_info()
     assert info["table_driven"] and info["staging"] == "global", info
+    phi_c, cdh_c, _ = run_hip(asora, c)  # default: column densities only in LDS, one 1024-thread workgroup per CU
+    info = asora.last_launch_info()
+    assert info["staging"] == "lds-compact" and info["block"] == 1024, info
+    assert np.array_equal(phi_c, phi) and np.array_equal(cdh_c, cdh)
     o = cases.run_oracle(port_oracle, c, heat=False, sens=True)
     r = compare(phi, o["phi_ion"], sens=o["phi_sens"])
     print(f"\n[fullbox256] max_rel={r['max_rel']:.3e} n_sens={r['n_sens']} support_equal={r['support_equal']}")

@@ -242,6 +242,27 @@ def test_source_order_is_free(asora, golden_dir):
     assert np.array_equal(res[1][1].reshape(N, N, N), out[2][1])
 
 
+@pytest.mark.parametrize("threads", [256, 512, 1024])
+@pytest.mark.parametrize("name", ["corner33", "lognormal48", "rcut7p3", "thick24"])
+def test_compact_staging_equals_pair_staging(asora, golden_dir, name, threads):
+    """Column-density-only staging (picked when the (column density, weight) pairs do not fit in LDS) recomputes
+    the weight 1/max(0.6, tau) from the same staged value with the same operation: bit-identical output."""
+    c = load_golden(golden_dir, name)
+    phi_n, cdh_n, _ = run_hip(asora, c, num_src=1)
+    assert asora.last_launch_info()["staging"] == "lds"
+    asora.set_option("compact_staging", 1)
+    asora.set_option("wg_threads", threads)
+    try:
+        phi_w, cdh_w, _ = run_hip(asora, c, num_src=1)
+        info = asora.last_launch_info()
+        assert info["block"] == threads and info["staging"] == "lds-compact" and info["table_driven"], info
+    finally:
+        asora.set_option("compact_staging", 0)
+        asora.set_option("wg_threads", 0)
+    assert np.array_equal(cdh_w, cdh_n)
+    assert np.array_equal(phi_w, phi_n)
+
+
 @pytest.mark.parametrize("name", ["multi16_unequal", "rcut7p3", "lognormal48", "corner33"])
 def test_skip_unobserved_cells(asora, golden_dir, name):
     """Option skip_unobserved (off by default; never used by bench.py): cells outside the R-sphere are not
