@@ -505,6 +505,10 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
                 if (waves > best_waves) { best_waves = waves; threads = t; }
                 if (waves >= 14) break;
             }
+            // few sources (single-source tests: 24 tasks): the chip is not full, so larger workgroups put
+            // more waves on each sector (128^3 full box, 1 source: 0.40 ms at 256 threads, 0.25 ms at 1024)
+            for (int t : sizes)
+                if (t > threads && A.ntasks * (t / 64) <= (long long)S.num_cu * 16) threads = t;
             use_lds = true;
         }
     }
