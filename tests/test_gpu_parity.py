@@ -263,6 +263,25 @@ def test_compact_staging_equals_pair_staging(asora, golden_dir, name, threads):
     assert np.array_equal(phi_w, phi_n)
 
 
+@pytest.mark.parametrize("opts", [dict(wg_threads=64), dict(wg_threads=1024), dict(wg_threads=512, compact_staging=1),
+                                  dict(skip_unobserved=1), dict(source_order=0)])
+def test_heat_output_of_the_kernel_variants(asora, golden_dir, opts):
+    """The heating rate rides on the same kernel variants: single source -> bit-identical phi, heat and
+    coldensh_out whatever workgroup size / staging layout / sweep options are picked."""
+    c = load_golden(golden_dir, "lognormal48")
+    assert bool(c["heat_valid"])
+    ref = run_hip(asora, c, heat=True, num_src=1)
+    for k, v in opts.items():
+        asora.set_option(k, v)
+    try:
+        out = run_hip(asora, c, heat=True, num_src=1)
+    finally:
+        for k in opts:
+            asora.set_option(k, 2 if k == "source_order" else 0)
+    for a, b in zip(out, ref):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("name", ["multi16_unequal", "rcut7p3", "lognormal48", "corner33"])
 def test_skip_unobserved_cells(asora, golden_dir, name):
     """Option skip_unobserved (off by default; never used by bench.py): cells outside the R-sphere are not
