@@ -41,7 +41,9 @@ def make_inputs(a):
     N = a.N
     fmin, fmax = 13.598 * EV / H_PLANCK, 54.416 * EV / H_PLANCK
     tau, dlogtau = make_tau_table(-20.0, 4.0, a.numtau)
-    thin, thick = BlackBodySource(1e5, False, fmin, 2.8).make_photo_table(tau, fmin, fmax, 1e48)
+    bb = BlackBodySource(1e5, False, fmin, 2.8)
+    thin, thick = bb.make_photo_table(tau, fmin, fmax, 1e48)
+    hthin, hthick = bb.make_heat_table(tau, fmin, fmax, 1e48) if a.heat else (None, None)
     rng = np.random.default_rng(918)
     if a.density == "uniform":
         ndens = np.full((N, N, N), 1e-3)
@@ -56,7 +58,8 @@ def make_inputs(a):
     # run_test.py:53-55: fact * uniform(1e9, 5e11) / 1e48 with fact ~ 4.09e40
     flux = 4.09e40 * rng.uniform(1e9, 5e11, a.sources) / 1e48
     xh = np.full((N, N, N), a.xh)
-    return dict(ndens=ndens, xh=xh, pos=pos, flux=flux, thin=thin, thick=thick, dlogtau=dlogtau)
+    return dict(ndens=ndens, xh=xh, pos=pos, flux=flux, thin=thin, thick=thick, hthin=hthin, hthick=hthick,
+                dlogtau=dlogtau)
 
 
 def cpu_baseline(a):
@@ -95,6 +98,7 @@ def main():
     ap.add_argument("--numtau", type=int, default=20000)
     ap.add_argument("--density", choices=["uniform", "clustered"], default="uniform")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--heat", action="store_true", help="also accumulate the photo-heating rate (not the headline config)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sources-per-core", type=int, default=48)  # ~15 s of CPU work per core
     a = ap.parse_args()
@@ -146,6 +150,11 @@ def main():
     asora.device_init(N, 64, dev_index, ngpu)
     asora.photo_table_to_device(np.ascontiguousarray(inp["thin"]), np.ascontiguousarray(inp["thick"]),
                                 inp["thin"].shape[0])
+    heat_t = None
+    if a.heat:
+        asora.heat_table_to_device(np.ascontiguousarray(inp["hthin"]), np.ascontiguousarray(inp["hthick"]),
+                                   inp["hthin"].shape[0])
+        heat_t = torch.zeros(N ** 3, dtype=torch.float64, device=dev)
     asora.density_from_device(ndens_t.data_ptr(), N)
     asora.source_data_to_device(np.ascontiguousarray(inp["pos"][lo:hi].ravel()),
                                 np.ascontiguousarray(inp["flux"][lo:hi]), ns_local)
@@ -153,11 +162,13 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        asora.do_all_sources_dev(a.R, 0, 6.30e-18, a.dr, xh_t.data_ptr(), phi_t.data_ptr(), 0, ns_local, N, -20.0,
-                                 inp["dlogtau"], num_tau, stream)
+        asora.do_all_sources_dev(a.R, 0, 6.30e-18, a.dr, xh_t.data_ptr(), phi_t.data_ptr(),
+                                 heat_t.data_ptr() if a.heat else 0, ns_local, N, -20.0, inp["dlogtau"], num_tau, stream)
         if world > 1:
             if dist.get_backend() == "nccl":
                 dist.all_reduce(phi_t)  # RCCL sum over xGMI, in place on device memory
+                if a.heat:
+                    dist.all_reduce(heat_t)
             else:  # single-GPU rehearsal only: through the host
                 h = phi_t.cpu()
                 dist.all_reduce(h)
@@ -198,12 +209,12 @@ def main():
     total_visits = float(visits) * a.sources
     value = total_visits * a.steps / dt
     k_ms = float(np.mean(kern_ms))
-    algo_bytes = (32.0 * visits + 16.0 * in_sphere) * ns_local
+    algo_bytes = (32.0 * visits + (32.0 if a.heat else 16.0) * in_sphere) * ns_local  # +16 B per heating-rate update
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
     info = asora.last_launch_info()
     traffic = None
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tf):
+    if os.path.exists(tf) and not a.heat and not rate_only:  # the counters were collected on the default path
         try:
             tj = json.load(open(tf))
             key = f"{a.density}_N{N}_R{a.R:g}_ns{ns_local}"
@@ -235,7 +246,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"raytracing_benchmark: {N}^3 {a.density} grid, {a.sources} sources, "
                                    f"R_max={a.R:g} cells, cell {a.dr:.4e} cm, xHII {a.xh:g}, NumTau {a.numtau}"
-                                   + (" [skip_unobserved: rate-producing cells only]" if rate_only else ""),
+                                   + (" [skip_unobserved: rate-producing cells only]" if rate_only else "")
+                                   + (" [+ photo-heating rate]" if a.heat else ""),
                        "visits_per_source": visits, "rate_visits_per_source": in_sphere,
                        "sources_per_gpu": ns_local, "parallelism": f"source-shard x{world} + all-reduce(phi_ion)",
                        "ns_per_source_per_sphere_cell": dt / a.steps / a.sources / (4.0 / 3.0 * np.pi * a.R ** 3) * 1e9,
