@@ -776,56 +776,79 @@ void sweep_tab_kernel(SweepArgs A) {
             double cdo[P], wo[P], ph[P], ht[HEAT ? P : 1], cin[P];
             int woff[P];
             bool fire[P], rate_slot[P];
-#pragma unroll
-            for (int q = 0; q < P; q++) {
+            // one slot: 4-point interpolation, new column density and its weight (raytracing.f90:662-813)
+            auto interp = [&](const int q, const bool plane1, const bool with_cdh) __attribute__((always_inline)) {
                 bool valid, isA;
                 (void)slot_index<NW>(d0, wave, q, lane, valid, isA);
-                const bool slot_on = d0.jbase + wave + q * NW < d0.nchunkA + d0.nchunkB;  // wave-uniform
-                fire[q] = false;
-                rate_slot[q] = slot_on && isA;
-                ph[q] = 0.0;
-                if (HEAT) ht[q] = 0.0;
-                woff[q] = -1;
-                cdo[q] = 0.0;
-                wo[q] = 0.0;
-                cin[q] = 0.0;
-                if (slot_on) {
-                    const uint2 m = meta_c[q];
-                    const uint32_t a = m.x & META_COORD_MASK, b = (m.x >> META_COORD_BITS) & META_COORD_MASK;
-                    const double2 du = du_tab[a], dv = dv_tab[b];
-                    const uint32_t o_up = m.y & 0xffffu, o_cur = m.y >> 16;
-                    const double2 e1 = C.stg.ld(o_up);       // (a-1, b-1)
-                    const double2 e3 = C.stg.ld(o_up + 1);   // (a-1, b)
-                    const double2 e2 = C.stg.ld(o_cur);      // (a,   b-1)
-                    const double2 e4 = C.stg.ld(o_cur + 1);  // (a,   b)
-                    // raytracing.f90:701-709 (weights read instead of recomputed)
-                    const double s1 = du.y * dv.y;
-                    const double s2 = dv.y * du.x;
-                    const double s3 = du.y * dv.x;
-                    const double s4 = du.x * dv.x;
-                    const double w1 = s1 * e1.y;
-                    const double w2 = s2 * e2.y;
-                    const double w3 = s3 * e3.y;
-                    const double w4 = s4 * e4.y;
-                    double cdh_in = div_exact(e1.x * w1 + e2.x * w2 + e3.x * w3 + e4.x * w4, w1 + w2 + w3 + w4);
-                    if (n == 1) {  // the 20 diagonal nearest neighbours, raytracing.f90:703-708
-                        if (a == 1 && b == 1) cdh_in = SQRT3_F32 * cdh_in;
-                        else if (a == 1 || b == 1) cdh_in = SQRT2_F32 * cdh_in;
-                    }
-                    const double c_out = cdh_in + nhi_c[q] * geo_c[q].x;
-                    cin[q] = cdh_in;
-                    cdo[q] = c_out;
-                    wo[q] = WSTAGED ? weightf(c_out, A.sig) : 0.0;
-                    woff[q] = valid ? (int)o_cur + 1 : -1;
-                    const bool ghost = ((m.x >> META_FLAG_SHIFT) & ghostmask) != 0;
-                    const bool own = valid && !ghost;
+                const uint2 m = meta_c[q];
+                const uint32_t a = m.x & META_COORD_MASK, b = (m.x >> META_COORD_BITS) & META_COORD_MASK;
+                const double2 du = du_tab[a], dv = dv_tab[b];
+                const uint32_t o_up = m.y & 0xffffu, o_cur = m.y >> 16;
+                const double2 e1 = C.stg.ld(o_up);       // (a-1, b-1)
+                const double2 e3 = C.stg.ld(o_up + 1);   // (a-1, b)
+                const double2 e2 = C.stg.ld(o_cur);      // (a,   b-1)
+                const double2 e4 = C.stg.ld(o_cur + 1);  // (a,   b)
+                // raytracing.f90:701-709 (weights read instead of recomputed)
+                const double s1 = du.y * dv.y;
+                const double s2 = dv.y * du.x;
+                const double s3 = du.y * dv.x;
+                const double s4 = du.x * dv.x;
+                const double w1 = s1 * e1.y;
+                const double w2 = s2 * e2.y;
+                const double w3 = s3 * e3.y;
+                const double w4 = s4 * e4.y;
+                double cdh_in = div_exact(e1.x * w1 + e2.x * w2 + e3.x * w3 + e4.x * w4, w1 + w2 + w3 + w4);
+                if (plane1) {  // the 20 diagonal nearest neighbours, raytracing.f90:703-708
+                    if (a == 1 && b == 1) cdh_in = SQRT3_F32 * cdh_in;
+                    else if (a == 1 || b == 1) cdh_in = SQRT2_F32 * cdh_in;
+                }
+                const double c_out = cdh_in + nhi_c[q] * geo_c[q].x;
+                cin[q] = cdh_in;
+                cdo[q] = c_out;
+                wo[q] = WSTAGED ? weightf(c_out, A.sig) : 0.0;
+                woff[q] = valid ? (int)o_cur + 1 : -1;
+                const bool ghost = ((m.x >> META_FLAG_SHIFT) & ghostmask) != 0;
+                const bool own = valid && !ghost;
+                if (with_cdh) {
                     if (cdh && own) *ptr_byte(cdh, g_c[q] * 8u) = c_out;
+                }
 #ifdef ASORA_ABL_NORATES
-                    fire[q] = own && isA && cdh_in == 1.2345e300;  // ablation build: column densities only
-                    rate_slot[q] = false;
+                fire[q] = own && isA && cdh_in == 1.2345e300;  // ablation build: column densities only
+                rate_slot[q] = false;
 #else
-                    fire[q] = own && isA && !(cdh_in > max_coldensh);
+                fire[q] = own && isA && !(cdh_in > max_coldensh);
+                rate_slot[q] = isA;
 #endif
+            };
+            const int nchunks = d0.nchunkA + d0.nchunkB;
+            const bool all_on = d0.jbase + wave + (P - 1) * NW < nchunks && n != 1 && !cdh;
+#if defined(ASORA_ABL_NORATES) || defined(ASORA_NO_RATE_BATCH)
+            const bool all_rates = false;
+#else
+            // (list A follows list B in the sequence; with the heating tables the batch would spill)
+            const bool all_rates = !HEAT && all_on && d0.jbase + wave >= d0.nchunkB;
+#endif
+            if (all_on) {
+                // the usual phase: every slot of this wave is occupied -> ONE basic block, so that the scheduler
+                // interleaves the slots' dependent chains (the column-density part is latency-bound)
+#pragma unroll
+                for (int q = 0; q < P; q++) {
+                    ph[q] = 0.0;
+                    if (HEAT) ht[q] = 0.0;
+                    interp(q, false, false);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < P; q++) {
+                    fire[q] = false;
+                    rate_slot[q] = false;
+                    ph[q] = 0.0;
+                    if (HEAT) ht[q] = 0.0;
+                    woff[q] = -1;
+                    cdo[q] = 0.0;
+                    wo[q] = 0.0;
+                    cin[q] = 0.0;
+                    if (d0.jbase + wave + q * NW < nchunks) interp(q, n == 1, true);  // wave-uniform
                 }
             }
             // ---- geometry + neutral density of the next phase: in flight during this phase's rates ------
@@ -839,18 +862,34 @@ void sweep_tab_kernel(SweepArgs A) {
                     nhi_n[q] = at_byte(nhi, g_n[q] * 8u);
                 }
             }
-            // rates, one slot at a time (keeps the live registers low); the two look-ups of a cell are in
-            // flight together
+            // rates: when every slot of the wave holds rate-producing cells, all of them together (their log10 /
+            // look-up chains interleave); otherwise one slot at a time
+            if (all_rates) {
+                RatePrep rp[P];
+                RateLoads rl[P];
 #pragma unroll
-            for (int q = 0; q < P; q++)
-                if (rate_slot[q]) {
-                    const RatePrep rp = rates_prepare(A, C.lg, flux, cin[q], cdo[q], geo_c[q].y);
-                    const RateLoads rl = rates_load<HEAT>(A, rp);
+                for (int q = 0; q < P; q++) rp[q] = rates_prepare(A, C.lg, flux, cin[q], cdo[q], geo_c[q].y);
+#pragma unroll
+                for (int q = 0; q < P; q++) rl[q] = rates_load<HEAT>(A, rp[q]);
+#pragma unroll
+                for (int q = 0; q < P; q++) {
                     double p_, h_ = 0.0;
-                    rates_finish<HEAT>(A, rp, rl, nhi_c[q], p_, h_);
+                    rates_finish<HEAT>(A, rp[q], rl[q], nhi_c[q], p_, h_);
                     ph[q] = p_;
                     if (HEAT) ht[q] = h_;
                 }
+            } else {
+#pragma unroll
+                for (int q = 0; q < P; q++)
+                    if (rate_slot[q]) {
+                        const RatePrep rp = rates_prepare(A, C.lg, flux, cin[q], cdo[q], geo_c[q].y);
+                        const RateLoads rl = rates_load<HEAT>(A, rp);
+                        double p_, h_ = 0.0;
+                        rates_finish<HEAT>(A, rp, rl, nhi_c[q], p_, h_);
+                        ph[q] = p_;
+                        if (HEAT) ht[q] = h_;
+                    }
+            }
             // ---- all atomics of the phase, after its last table look-up --------------------------
 #pragma unroll
             for (int q = 0; q < P; q++) {
