@@ -820,6 +820,9 @@ void sweep_tab_kernel(SweepArgs A) {
                 rate_slot[q] = isA;
 #endif
             };
+            // wave priority: low while interpolating, high from the rates to the end of the phase -- a wave close to
+            // the barrier its workgroup waits at goes first (0.6 %)
+            __builtin_amdgcn_s_setprio(0);
             const int nchunks = d0.nchunkA + d0.nchunkB;
             const bool all_on = d0.jbase + wave + (P - 1) * NW < nchunks && n != 1 && !cdh;
 #if defined(ASORA_ABL_NORATES) || defined(ASORA_NO_RATE_BATCH)
@@ -862,6 +865,7 @@ void sweep_tab_kernel(SweepArgs A) {
                     nhi_n[q] = at_byte(nhi, g_n[q] * 8u);
                 }
             }
+            __builtin_amdgcn_s_setprio(2);
             // rates: when every slot of the wave holds rate-producing cells, all of them together (their log10 /
             // look-up chains interleave); otherwise one slot at a time
             if (all_rates) {
