@@ -1,0 +1,40 @@
+"""The N > 1 path of bench.py on the GPU: two ranks (one GPU here, so the all-reduce goes through gloo and
+the host -- ASORA_BENCH_BACKEND=gloo; RCCL refuses two ranks on one device) shard the source list and
+must reproduce the single-rank rate grid."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--N", "64", "--sources", "481", "--R", "20", "--no-cpu", "--steps", "1", "--warmup", "1"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _last_json(out):
+    return json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_reproduces_single_rank_checksum():
+    env = dict(os.environ, ASORA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *ARGS], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", *ARGS], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = _last_json(one.stdout), _last_json(two.stdout)
+    assert b["n_gpus"] == 2 and b["config"]["sources_per_gpu"] in (240, 241)
+    ca, cb = a["config"]["phi_checksum"], b["config"]["phi_checksum"]
+    assert ca > 0 and abs(ca - cb) <= 1e-12 * ca, (ca, cb)  # sum order differs, nothing else
