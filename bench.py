@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--numtau", type=int, default=20000)
     ap.add_argument("--density", choices=["uniform", "clustered"], default="uniform")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--shard-order", choices=["curve", "list"], default="curve",
+                    help="N > 1: shard the source list after sorting it along the library's Hilbert curve "
+                         "(spatially compact shards) or as given")
     ap.add_argument("--heat", action="store_true", help="also accumulate the photo-heating rate (not the headline config)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sources-per-core", type=int, default=48)  # ~15 s of CPU work per core
@@ -137,7 +140,15 @@ def main():
         a.sources = a.sources * world
     inp = make_inputs(a)
     N = a.N
-    lo, hi = shard_sources(a.sources, rank, world)
+    # single-GPU rehearsal of one rank's share of an N-GPU run: ASORA_BENCH_EMULATE="rank/world"
+    emu = os.environ.get("ASORA_BENCH_EMULATE")
+    shard_rank, shard_world = (int(x) for x in emu.split("/")) if emu else (rank, world)
+    if shard_world > 1 and a.shard_order == "curve":
+        # source-list preprocessing, once, outside the timed steps: contiguous shards of the
+        # curve-sorted list are spatially compact, so the sources a GPU has in flight share more of their reads
+        order = asora.source_order(np.ascontiguousarray(inp["pos"].ravel()), N, 2)
+        inp["pos"], inp["flux"] = inp["pos"][order], inp["flux"][order]
+    lo, hi = shard_sources(a.sources, shard_rank, shard_world)
     ns_local = hi - lo
     dev = torch.device("cuda", dev_index)
     ndens_t = torch.from_numpy(inp["ndens"].ravel()).to(dev)
@@ -206,7 +217,7 @@ def main():
     rate_only = "skip_unobserved=1" in os.environ.get("ASORA_OPTIONS", "")
     if rate_only:  # experiment only: the cells outside the R-sphere are not swept, so they are not counted either
         visits = in_sphere
-    total_visits = float(visits) * a.sources
+    total_visits = float(visits) * (ns_local if emu else a.sources)  # rehearsal: this GPU's share only
     value = total_visits * a.steps / dt
     k_ms = float(np.mean(kern_ms))
     algo_bytes = (32.0 * visits + (32.0 if a.heat else 16.0) * in_sphere) * ns_local  # +16 B per heating-rate update
@@ -247,7 +258,8 @@ def main():
             "config": {"workload": f"raytracing_benchmark: {N}^3 {a.density} grid, {a.sources} sources, "
                                    f"R_max={a.R:g} cells, cell {a.dr:.4e} cm, xHII {a.xh:g}, NumTau {a.numtau}"
                                    + (" [skip_unobserved: rate-producing cells only]" if rate_only else "")
-                                   + (" [+ photo-heating rate]" if a.heat else ""),
+                                   + (" [+ photo-heating rate]" if a.heat else "")
+                                   + (f" [rehearsal of rank {emu}]" if emu else ""),
                        "visits_per_source": visits, "rate_visits_per_source": in_sphere,
                        "sources_per_gpu": ns_local, "parallelism": f"source-shard x{world} + all-reduce(phi_ion)",
                        "ns_per_source_per_sphere_cell": dt / a.steps / a.sources / (4.0 / 3.0 * np.pi * a.R ** 3) * 1e9,
