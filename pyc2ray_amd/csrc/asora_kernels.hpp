@@ -577,7 +577,7 @@ __device__ __forceinline__ double2 interp_offsets(int i, int s, int x1, double a
 struct PhaseDesc {
     int n, jbase;
     uint32_t off;
-    int cntA, cntT, nchunkA, nchunkB;
+    int cntA, cntT, nchunkA, nchunk;  // nchunk chunks in all; the first nchunkA of them hold rate-producing cells
     bool valid;
 };
 __device__ __forceinline__ void phase_load_plane(PhaseDesc &d, const PlaneInfo *planes, int nmax, bool rate_only) {
@@ -588,31 +588,39 @@ __device__ __forceinline__ void phase_load_plane(PhaseDesc &d, const PlaneInfo *
         d.cntA = (int)pi.cntA;
         d.cntT = rate_only ? (int)pi.cntA : (int)pi.cntT;
         d.nchunkA = (d.cntA + 63) >> 6;
-        d.nchunkB = (d.cntT - d.cntA + 63) >> 6;
+        d.nchunk = (d.cntT + 63) >> 6;
     }
 }
 template <int STEP>
 __device__ __forceinline__ PhaseDesc phase_next(PhaseDesc d, const PlaneInfo *planes, int nmax, bool rate_only) {
     if (!d.valid) return d;
     d.jbase += STEP;
-    if (d.jbase >= d.nchunkA + d.nchunkB) {
+    if (d.jbase >= d.nchunk) {
         d.n++;
         d.jbase = 0;
         phase_load_plane(d, planes, nmax, rate_only);
     }
     return d;
 }
-// slot q of this wave in phase d: table index of the lane's cell (0 when the lane has none)
+// slot q of this wave in phase d: table index of the lane's cell (0 when the lane has none).  A plane's cells --
+// list A (rate-producing) followed by list B -- are ONE sequence cut into 64-cell chunks, taken from the last
+// chunk down; the chunk that straddles the two lists counts as rate-producing (its B lanes never fire).
+// rates: wave-uniform, the chunk holds cells of list A; isA: this lane's cell is one of them.
+template <int NW>
+__device__ __forceinline__ uint32_t slot_index(const PhaseDesc &d, int wave, int q, int lane, bool &valid, bool &isA,
+                                               bool &rates) {
+    const int jj = d.jbase + wave + q * NW;  // wave-uniform
+    const int c = d.nchunk - 1 - jj;
+    const int i = c * 64 + lane;
+    rates = c < d.nchunkA;
+    isA = i < d.cntA;
+    valid = d.valid && (jj < d.nchunk) && (i < d.cntT);
+    return (uint32_t)(valid ? i : 0);
+}
 template <int NW>
 __device__ __forceinline__ uint32_t slot_index(const PhaseDesc &d, int wave, int q, int lane, bool &valid, bool &isA) {
-    const int jj = d.jbase + wave + q * NW;  // wave-uniform
-    // decreasing order: B chunks from the last down, then A chunks from the last down
-    isA = jj >= d.nchunkB;
-    const int c = isA ? d.nchunkA - 1 - (jj - d.nchunkB) : d.nchunkB - 1 - jj;
-    const int i = isA ? c * 64 + lane : d.cntA + c * 64 + lane;
-    const int lim = isA ? d.cntA : d.cntT;
-    valid = d.valid && (jj < d.nchunkA + d.nchunkB) && (i < lim);
-    return (uint32_t)(valid ? i : 0);
+    bool rates;
+    return slot_index<NW>(d, wave, q, lane, valid, isA, rates);
 }
 
 // The sweep is latency-bound (rocprofv3: waves wait 73 % of their cycles; an ablation without the
@@ -700,7 +708,7 @@ void sweep_tab_kernel(SweepArgs A) {
 
         // phase descriptors of p and p+1, cell coordinates of p
         PhaseDesc d0, d1;
-        d0.n = 1; d0.jbase = 0; d0.off = 0; d0.cntA = d0.cntT = d0.nchunkA = d0.nchunkB = 0;
+        d0.n = 1; d0.jbase = 0; d0.off = 0; d0.cntA = d0.cntT = d0.nchunkA = d0.nchunk = 0;
         phase_load_plane(d0, planes, nmax, rate_only);
         d1 = phase_next<NW * P>(d0, planes, nmax, rate_only);
         uint2 meta_c[P], meta_n[P];
@@ -778,8 +786,8 @@ void sweep_tab_kernel(SweepArgs A) {
             bool fire[P], rate_slot[P];
             // one slot: 4-point interpolation, new column density and its weight (raytracing.f90:662-813)
             auto interp = [&](const int q, const bool plane1, const bool with_cdh) __attribute__((always_inline)) {
-                bool valid, isA;
-                (void)slot_index<NW>(d0, wave, q, lane, valid, isA);
+                bool valid, isA, rates;
+                (void)slot_index<NW>(d0, wave, q, lane, valid, isA, rates);
                 const uint2 m = meta_c[q];
                 const uint32_t a = m.x & META_COORD_MASK, b = (m.x >> META_COORD_BITS) & META_COORD_MASK;
                 const double2 du = du_tab[a], dv = dv_tab[b];
@@ -817,19 +825,19 @@ void sweep_tab_kernel(SweepArgs A) {
                 rate_slot[q] = false;
 #else
                 fire[q] = own && isA && !(cdh_in > max_coldensh);
-                rate_slot[q] = isA;
+                rate_slot[q] = rates;
 #endif
             };
             // wave priority: low while interpolating, high from the rates to the end of the phase -- a wave close to
             // the barrier its workgroup waits at goes first (0.6 %)
             __builtin_amdgcn_s_setprio(0);
-            const int nchunks = d0.nchunkA + d0.nchunkB;
+            const int nchunks = d0.nchunk;
             const bool all_on = d0.jbase + wave + (P - 1) * NW < nchunks && n != 1 && !cdh;
 #if defined(ASORA_ABL_NORATES) || defined(ASORA_NO_RATE_BATCH)
             const bool all_rates = false;
 #else
-            // (list A follows list B in the sequence; with the heating tables the batch would spill)
-            const bool all_rates = !HEAT && all_on && d0.jbase + wave >= d0.nchunkB;
+            // (slot 0 holds the wave's highest chunk; with the heating tables the batch would spill)
+            const bool all_rates = !HEAT && all_on && d0.nchunk - 1 - (d0.jbase + wave) < d0.nchunkA;
 #endif
             if (all_on) {
                 // the usual phase: every slot of this wave is occupied -> ONE basic block, so that the scheduler
