@@ -214,7 +214,7 @@ void make_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
         auto pos = [&](int a, int b) { return (uint32_t)(rowoff[a + 1] + b + 1); };
         planes.resize(planes.size() + nplanes);
         asora::PlaneInfo *pl = planes.data() + planes.size() - nplanes;
-        pl[0] = {pos(0, 0), 0, (uint32_t)entries, 0};
+        pl[0] = {pos(0, 0), 0, (uint32_t)entries, 0, 0.0};
         for (int n = 1; n <= nmaxmax; n++) {
             const int cut = q_max - n;
             const int H = std::min(std::min(n, LU), cut) + 1, W = std::min(std::min(n, LV), cut) + 1;
@@ -222,6 +222,7 @@ void make_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
             const double P2 = (dr * dn) * (dr * dn);
             pl[n].off = (uint32_t)meta.size();
             pl[n].pad = 0;
+            pl[n].alam = (dn - 0.5) / dn;  // raytracing.f90:683 with |dk| = n
             for (int pass = 0; pass < 2; pass++) {
                 for (int a = 0; a < H; a++) {
                     const int bend = std::min(W - 1, cut - a);
@@ -454,7 +455,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         for (int i = 0; i < 8; i++) A.vmap[i] = S.geo_vmap[i];
         lds_stage = (size_t)A.cw_entries * 2 * sizeof(double);
         lds_stage_c = (size_t)((A.cw_entries + 1) & ~1) * sizeof(double);  // column densities only
-        lds_fixed = (size_t)(5 * A.wtab + (A.wtab & 1) + 2 * A.nplanes) * sizeof(double) + lds_log;
+        lds_fixed = (size_t)(5 * A.wtab + (A.wtab & 1) + asora::PLANE_INFO_DOUBLES * A.nplanes) * sizeof(double) + lds_log;
     } else {
         lds_stage = 2 * (size_t)A.plane_elems * sizeof(double);  // table-free kernel: two square planes
         lds_fixed = lds_log;

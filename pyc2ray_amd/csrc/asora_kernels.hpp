@@ -56,9 +56,12 @@ constexpr double SQRT2_CUDA = 1.41421356237;
 // One plane of one geometry variant in the cell tables: cells [off, off+cntA) produce rates
 // (dist2/dr2 <= R2 with the oracle's exact arithmetic), [off+cntA, off+cntT) only propagate cdh.
 // Entry 0 of a variant (the source plane) holds off = staging position of cell (0, 0).
+// alam = (n - 1/2) / n (raytracing.f90:683), the same for every cell of plane n.
 struct PlaneInfo {
     uint32_t off, cntA, cntT, pad;
+    double alam;
 };
+constexpr int PLANE_INFO_DOUBLES = sizeof(PlaneInfo) / sizeof(double);
 
 struct SweepArgs {
     const double *nhiA;  // nHI, [i][j][k]
@@ -668,7 +671,7 @@ void sweep_tab_kernel(SweepArgs A) {
     // the variant's plane table: read through LDS so that stepping to the next plane never touches vmcnt
     PlaneInfo *const planes = reinterpret_cast<PlaneInfo *>(asora_smem + off_du + 5 * W + (W & 1));
     C.stg.g = LDS_STAGE ? nullptr : reinterpret_cast<double2 *>(A.gscratch) + (size_t)blockIdx.x * (size_t)E;
-    C.lg = load_log10_table(A.log10_table, off_du + 5 * W + (W & 1) + 2 * A.nplanes, tid, THREADS);
+    C.lg = load_log10_table(A.log10_table, off_du + 5 * W + (W & 1) + PLANE_INFO_DOUBLES * A.nplanes, tid, THREADS);
     const double w_empty = weightf(0.0, A.sig);  // weight of a guard / never-written entry
 
     for (long long task = blockIdx.x; task < A.ntasks; task += gridDim.x) {
@@ -725,7 +728,7 @@ void sweep_tab_kernel(SweepArgs A) {
             colV[i] = wrap(v0 + sv * i, N);
         }
         {
-            const double alam = cinterp_alam(1);
+            const double alam = planes[1].alam;
             for (int i = tid; i < 2 * W; i += THREADS) {
                 if (i < W) du_tab[i] = interp_offsets(i, su, u0 + 1, alam);
                 else dv_tab[i - W] = interp_offsets(i - W, sv, v0 + 1, alam);
@@ -919,7 +922,7 @@ void sweep_tab_kernel(SweepArgs A) {
             for (int q = 0; q < P; q++)
                 if (woff[q] >= 0) C.stg.st((uint32_t)woff[q], cdo[q], wo[q]);
             if (d1.n != n) {  // last phase of this plane: interpolation offsets of the next one
-                const double alam_next = cinterp_alam(n + 1);
+                const double alam_next = planes[min(n + 1, A.nplanes - 1)].alam;
                 for (int i = tid; i < 2 * W; i += THREADS) {
                     if (i < W) du_tab[i] = interp_offsets(i, su, u0 + 1, alam_next);
                     else dv_tab[i - W] = interp_offsets(i - W, sv, v0 + 1, alam_next);
