@@ -22,7 +22,7 @@ VARIANTS = [dict(), dict(wg_threads=64), dict(wg_threads=128), dict(wg_threads=1
             dict(force_generic=1), dict(source_order=0), dict(skip_unobserved=1), dict(lds_stage_limit=1024)]
 
 
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", range(96))
 def test_random_small_case_vs_oracle(asora, port_oracle, seed):
     rng = np.random.default_rng(9000 + seed)
     N = MESHES[seed % len(MESHES)]
@@ -37,14 +37,18 @@ def test_random_small_case_vs_oracle(asora, port_oracle, seed):
     opts = VARIANTS[seed % len(VARIANTS)]
     for k, v in opts.items():
         asora.set_option(k, v)
+    with_heat = seed % 3 == 0
     try:
-        phi, cdh, _ = run_hip(asora, c)
+        phi, cdh, heat = run_hip(asora, c, heat=with_heat)
     finally:
         for k in opts:
             asora.set_option(k, 2 if k == "source_order" else 0)
-    o = cases.run_oracle(port_oracle, c, heat=False, sens=True)
+    o = cases.run_oracle(port_oracle, c, heat=with_heat, sens=True)
     r = compare(phi, o["phi_ion"], sens=o["phi_sens"])
     assert r["ok"] and r["support_equal"], (N, R, ns, opts, r)
+    if with_heat:
+        rh = compare(heat, o["phi_heat"], sens=o["heat_sens"])
+        assert rh["ok"], (N, R, ns, opts, rh)
     # column density of the last source: bit-identical wherever both swept
     last = dict(c, pos=c["pos"][-1:], flux=c["flux"][-1:])
     ol = cases.run_oracle(port_oracle, last, heat=False)
