@@ -29,6 +29,8 @@ import time
 
 import numpy as np
 
+# the host driver only supports dmabuf IPC (RCCL between processes); set before any HIP runtime loads
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
