@@ -99,8 +99,10 @@ def test_evolve_step_vs_golden(golden_dir, skip_unobserved):
 
 
 def test_evolve_two_steps_shadow128_vs_oracle(port_oracle):
-    """BASELINE config 3: two consecutive evolve steps (raytrace + chemistry to convergence) of the 128^3
-    shadow test, device loop vs the same host loop driven by the CPU oracle.  Bar: xHII <= 1e-8."""
+    """BASELINE config 3: consecutive evolve steps (raytrace + chemistry to convergence) of the 128^3
+    shadow test, device loop vs the same host loop driven by the CPU oracle.  Bar: xHII <= 1e-8.
+    Two steps by default; ASORA_TEST_EVOLVE_STEPS=10 runs the whole test problem (about a minute of oracle time)."""
+    nsteps = int(os.environ.get("ASORA_TEST_EVOLVE_STEPS", "2"))
     from evolve_host import evolve3D_host
     from pyc2ray_amd import asora_core
     from pyc2ray_amd.evolve import evolve3D
@@ -110,7 +112,7 @@ def test_evolve_two_steps_shadow128_vs_oracle(port_oracle):
     asora_core.device_init(N, 8, 0, 1)
     try:
         asora_core.photo_table_to_device(c["thin"], c["thick"])
-        for step in range(2):
+        for step in range(nsteps):
             hist = []
             xh_gpu, phi, _ = evolve3D(c["dt"], c["dr"], c["flux"], c["pos"].T, True, 0, 0, 0.0, False, None, 0, 1,
                                       c["temp"], c["ndens"], xh_gpu, c["clump"], c["thin"], c["thick"],
