@@ -138,7 +138,9 @@ int asora_source_order(const int32_t *pos, int num_src, int m1, int order, int32
  * recorded on the launch stream (synchronises on the stop event). */
 int asora_last_sweep_ms(float *ms);
 
-/* Name of the sweep kernel and its launch geometry of the last call (for profile matching). */
+/* Launch geometry of the last sweep (for profile matching): workgroups, threads per workgroup, dynamic LDS
+ * bytes per workgroup, and where the staged column densities lived: 0 global scratch, 1 LDS as (column
+ * density, weight) pairs, 2 LDS as column densities only. */
 int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_is_lds);
 
 /* Tuning / test switches: "force_generic" (1: always run the table-free sweep kernel),
