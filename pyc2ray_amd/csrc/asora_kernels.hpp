@@ -476,11 +476,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
 // overwritten by an earlier phase.  Positions a plane does not write (beyond the octahedron cut)
 // are never read later with non-zero weight; never-written positions and guards hold (0, 1/0.6).
 // ------------------------------------------------------------------------------------------
-#ifndef ASORA_GROUP
-#define ASORA_GROUP 1
-#endif
 // chunks per wave per phase.  Measured on the 256^3 / R = 60 sweep (4 waves per SIMD, ms per 1e4 sources):
-// 1: 135, 2: 121 (122 VGPRs, no spills), 3: 122, 4: 292 (spills)
+// 1: 135, 2: 121 (no spills), 3: 122, 4: 292 (spills); with the branch-free fast path: 2: 100, 3: 103
 #ifndef ASORA_PHASE_CHUNKS
 #define ASORA_PHASE_CHUNKS 2
 #endif
