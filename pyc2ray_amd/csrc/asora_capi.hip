@@ -76,6 +76,9 @@ struct State {
     int lds_stage_limit = 0;      // option "lds_stage_limit": larger staging arrays go to global memory (0: automatic)
     int lds_pad = 0;              // option "lds_pad": extra dynamic LDS per workgroup (occupancy experiments)
     int wg_threads = 0;           // option "wg_threads": workgroup size of the table-driven kernel, 256/512/1024 (0: automatic)
+    int quad_kernel = 0;          // option "quad_kernel": four quadrants per workgroup (0: automatic, 1: whenever possible, -1: never)
+    int quad_max_entries = 1100;  // option "quad_max_entries": automatic choice up to this many staged entries per quadrant (R <~ 41)
+    int last_quad = 0;
     int compact_staging = 0;      // option "compact_staging": stage column densities only (0: automatic, 1: always, -1: never)
     int skip_unobserved = 0;      // option "skip_unobserved": cells outside the R-sphere only for the exported column density
     int force_generic = 0;        // option "force_generic": always use the table-free kernel
@@ -278,12 +281,12 @@ int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
     return 0;
 }
 
-template <bool L, bool H, int T, bool WS = true>
+template <bool L, bool H, int T, bool WS = true, bool QD = false>
 int launch_sweep_tab(const asora::SweepArgs &A, int grid, size_t lds, hipStream_t st) {
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)asora::sweep_tab_kernel<L, H, T, WS>,
+        HIP_TRY(hipFuncSetAttribute((const void *)asora::sweep_tab_kernel<L, H, T, WS, QD>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((asora::sweep_tab_kernel<L, H, T, WS>), dim3(grid), dim3(T), lds, st, A);
+    hipLaunchKernelGGL((asora::sweep_tab_kernel<L, H, T, WS, QD>), dim3(grid), dim3(T), lds, st, A);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -422,7 +425,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     A.src_pos = S.src_pos; A.src_flux = S.src_flux;
     A.thick = S.thick; A.thin = S.thin; A.hthick = S.hthick; A.hthin = S.hthin;
     A.log10_table = S.log10_table;
-    A.ntasks = (long long)asora::SECTORS * num_src;
+    A.ntasks = (long long)asora::SECTORS * num_src;  // (a quarter of that for the four-quadrant kernel, set below)
     A.src_begin = 0;
     A.cdh_src = want_cdh ? S.staged_last : -1;
     A.N = N;
@@ -447,15 +450,33 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         if (S.geo_entries > 65535) use_tab = false;
     }
     size_t lds_stage, lds_stage_c = 0, lds_fixed;
+    bool quad = false;
     if (use_tab) {
         // ONE packed array of (column density, weight) pairs, updated in place, + per-row/column tables
         A.planes = S.planes_dev; A.cell_meta = S.cell_meta_dev; A.cell_geo = S.cell_geo_dev;
         A.nplanes = S.geo_nplanes; A.cw_entries = S.geo_entries;
         A.rate_only = S.skip_unobserved ? 1 : 0; A.nmax_rate = S.geo_nmax_rate;
         for (int i = 0; i < 8; i++) A.vmap[i] = S.geo_vmap[i];
-        lds_stage = (size_t)A.cw_entries * 2 * sizeof(double);
-        lds_stage_c = (size_t)((A.cw_entries + 1) & ~1) * sizeof(double);  // column densities only
-        lds_fixed = (size_t)(5 * A.wtab + (A.wtab & 1) + asora::PLANE_INFO_DOUBLES * A.nplanes) * sizeof(double) + lds_log;
+        // four-quadrant kernel (small radii): the quadrants of a pyramid must share their geometry variant, and four
+        // staging arrays must fit in LDS
+        quad = S.quad_kernel >= 0 && num_src > 0 && S.lds_stage_limit <= 0;
+        for (int i = 2; i < 8; i++) quad = quad && S.geo_vmap[i] == S.geo_vmap[i & 1];
+        if (quad && S.quad_kernel == 0)  // automatic: small radii, and no workgroup size forced that the variant lacks
+            quad = A.cw_entries <= S.quad_max_entries &&
+                   (S.wg_threads == 0 || S.wg_threads == 64 || S.wg_threads == 128 || S.wg_threads == 256);
+        for (int pass = 0; pass < 2; pass++) {
+            const size_t nq = quad ? 4 : 1, sw = (size_t)(quad ? 2 : 1) * A.wtab;
+            lds_stage = nq * (size_t)A.cw_entries * 2 * sizeof(double);
+            lds_stage_c = nq * (size_t)((A.cw_entries + 1) & ~1) * sizeof(double);  // column densities only
+            lds_fixed = (size_t)(5 * sw + (sw & 1) + asora::PLANE_INFO_DOUBLES * A.nplanes) * sizeof(double) + lds_log;
+            if (!quad || std::min(lds_stage, S.compact_staging >= 0 ? lds_stage_c : lds_stage) + lds_fixed +
+                                 (size_t)S.lds_pad <= (size_t)S.max_lds)
+                break;
+            if (S.quad_kernel > 0)
+                return fail(13, "asora_do_all_sources: the four-quadrant kernel does not fit in LDS at this radius");
+            quad = false;
+        }
+        if (quad) A.ntasks = (long long)(asora::SECTORS / 4) * num_src;
     } else {
         lds_stage = 2 * (size_t)A.plane_elems * sizeof(double);  // table-free kernel: two square planes
         lds_fixed = lds_log;
@@ -479,7 +500,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     bool compact = false;
     if (use_tab && S.lds_stage_limit <= 0 && S.compact_staging >= 0 &&
         lds_stage_c + lds_fixed + (size_t)S.lds_pad <= (size_t)S.max_lds &&
-        (S.compact_staging > 0 || lds_stage + lds_fixed + (size_t)S.lds_pad > (size_t)S.max_lds / 2)) {
+        (S.compact_staging > 0 || lds_stage + lds_fixed + (size_t)S.lds_pad > (size_t)S.max_lds / (quad ? 3 : 2))) {
         compact = true;
         lds_stage = lds_stage_c;
     }
@@ -490,8 +511,8 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         if (S.wg_threads == 64 || S.wg_threads == 128 || S.wg_threads == 192 || S.wg_threads == 256 ||
             S.wg_threads == 512 || S.wg_threads == 1024) {
             threads = S.wg_threads;
-            if (compact && threads < 256) return fail(13, "asora_do_all_sources: compact staging needs wg_threads >= 256");
-            if (threads != 256 || compact) {
+            if (compact && threads < 256 && !quad) return fail(13, "asora_do_all_sources: compact staging needs wg_threads >= 256");
+            if (threads != 256 || compact || quad) {
                 if (full > (size_t)S.max_lds) return fail(13, "asora_do_all_sources: wg_threads=%d needs %zu B of LDS", threads, full);
                 use_lds = true;
             }
@@ -501,7 +522,8 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             const int fit = (int)((size_t)S.max_lds / ((full + 1023) & ~(size_t)1023));
             int best_waves = 0;
             for (int t : sizes) {
-                if (compact && t < 256) continue;
+                if (compact && t < 256 && !quad) continue;
+                if (quad && (t == 192 || t > 256)) continue;
                 const int waves = std::min(fit, 16 / (t / 64)) * (t / 64);
                 if (waves > best_waves) { best_waves = waves; threads = t; }
                 if (waves >= 14) break;
@@ -509,7 +531,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             // few sources (single-source tests: 24 tasks): the chip is not full, so larger workgroups put
             // more waves on each sector (128^3 full box, 1 source: 0.40 ms at 256 threads, 0.25 ms at 1024)
             for (int t : sizes)
-                if (t > threads && A.ntasks * (t / 64) <= (long long)S.num_cu * 16) threads = t;
+                if (t > threads && !(quad && (t == 192 || t > 256)) && A.ntasks * (t / 64) <= (long long)S.num_cu * 16) threads = t;
             use_lds = true;
         }
     }
@@ -539,7 +561,15 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             constexpr int T = asora::SWEEP_THREADS;
 #define ASORA_LAUNCH_TAB(L, TH, WS) \
     (want_heat ? launch_sweep_tab<L, true, TH, WS>(A, grid, lds, st) : launch_sweep_tab<L, false, TH, WS>(A, grid, lds, st))
-            if (compact) {
+#define ASORA_LAUNCH_QUAD(TH, WS) \
+    (want_heat ? launch_sweep_tab<true, true, TH, WS, true>(A, grid, lds, st) \
+               : launch_sweep_tab<true, false, TH, WS, true>(A, grid, lds, st))
+            if (quad) {
+                if (threads == 64) rc = compact ? ASORA_LAUNCH_QUAD(64, false) : ASORA_LAUNCH_QUAD(64, true);
+                else if (threads == 128) rc = compact ? ASORA_LAUNCH_QUAD(128, false) : ASORA_LAUNCH_QUAD(128, true);
+                else if (threads == 256) rc = compact ? ASORA_LAUNCH_QUAD(256, false) : ASORA_LAUNCH_QUAD(256, true);
+                else return fail(13, "asora_do_all_sources: the four-quadrant kernel runs 64, 128 or 256 threads");
+            } else if (compact) {
                 if (threads == 1024) rc = ASORA_LAUNCH_TAB(true, 1024, false);
                 else if (threads == 512) rc = ASORA_LAUNCH_TAB(true, 512, false);
                 else rc = ASORA_LAUNCH_TAB(true, T, false);
@@ -551,6 +581,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             else if (use_lds) rc = ASORA_LAUNCH_TAB(true, T, true);
             else rc = ASORA_LAUNCH_TAB(false, T, true);
 #undef ASORA_LAUNCH_TAB
+#undef ASORA_LAUNCH_QUAD
         } else {
             if (use_lds) rc = want_heat ? launch_sweep<true, true>(A, grid, lds, st) : launch_sweep<true, false>(A, grid, lds, st);
             else rc = want_heat ? launch_sweep<false, true>(A, grid, lds, st) : launch_sweep<false, false>(A, grid, lds, st);
@@ -559,7 +590,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         HIP_TRY(hipEventRecord(S.ev1, st));
         S.timed = true;
         S.last_grid = grid; S.last_block = use_tab ? threads : asora::SWEEP_THREADS; S.last_lds = (int)lds;
-        S.last_is_lds = use_lds ? (compact ? 2 : 1) : 0;
+        S.last_is_lds = (use_lds ? (compact ? 2 : 1) : 0) | (quad ? 4 : 0);
     }
 
     hipLaunchKernelGGL(asora::finalize_kernel, tg, tb, 0, st, S.phiA, S.phiB, phi_out_dev, N);
@@ -663,7 +694,7 @@ int asora_device_close(void) {
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     State fresh;  // options and the last launch record survive a close
-    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.compact_staging = S.compact_staging; fresh.max_table_cells = S.max_table_cells;
+    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.compact_staging = S.compact_staging; fresh.quad_kernel = S.quad_kernel; fresh.quad_max_entries = S.quad_max_entries; fresh.last_quad = S.last_quad; fresh.max_table_cells = S.max_table_cells;
     fresh.last_tab = S.last_tab; fresh.last_grid = S.last_grid; fresh.last_block = S.last_block;
     fresh.last_lds = S.last_lds; fresh.last_is_lds = S.last_is_lds;
     S = fresh;
@@ -923,6 +954,8 @@ int asora_set_option(const char *name, long long value) {
     else if (!std::strcmp(name, "lds_stage_limit")) S.lds_stage_limit = (int)value;
     else if (!std::strcmp(name, "wg_threads")) S.wg_threads = (int)value;
     else if (!std::strcmp(name, "source_order")) S.source_order = (int)value;
+    else if (!std::strcmp(name, "quad_kernel")) S.quad_kernel = (int)value;
+    else if (!std::strcmp(name, "quad_max_entries")) S.quad_max_entries = (int)value;
     else if (!std::strcmp(name, "compact_staging")) S.compact_staging = (int)value;
     else if (!std::strcmp(name, "skip_unobserved")) S.skip_unobserved = value != 0;
     else return fail(12, "asora_set_option: unknown option '%s'", name);

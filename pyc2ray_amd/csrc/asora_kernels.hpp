@@ -580,6 +580,9 @@ struct PhaseDesc {
     int cntA, cntT, nchunkA, nchunk;  // nchunk chunks in all; the first nchunkA of them hold rate-producing cells
     bool valid;
 };
+// QS: log2 of the sectors a wavefront works on side by side (0, or 2 in the four-quadrant kernel): a chunk of
+// 64 lanes then holds 64 >> QS cells, each for 1 << QS quadrants.
+template <int QS>
 __device__ __forceinline__ void phase_load_plane(PhaseDesc &d, const PlaneInfo *planes, int nmax, bool rate_only) {
     d.valid = d.n <= nmax;
     if (d.valid) {
@@ -587,18 +590,18 @@ __device__ __forceinline__ void phase_load_plane(PhaseDesc &d, const PlaneInfo *
         d.off = pi.off;
         d.cntA = (int)pi.cntA;
         d.cntT = rate_only ? (int)pi.cntA : (int)pi.cntT;
-        d.nchunkA = (d.cntA + 63) >> 6;
-        d.nchunk = (d.cntT + 63) >> 6;
+        d.nchunkA = (d.cntA + (64 >> QS) - 1) >> (6 - QS);
+        d.nchunk = (d.cntT + (64 >> QS) - 1) >> (6 - QS);
     }
 }
-template <int STEP>
+template <int STEP, int QS>
 __device__ __forceinline__ PhaseDesc phase_next(PhaseDesc d, const PlaneInfo *planes, int nmax, bool rate_only) {
     if (!d.valid) return d;
     d.jbase += STEP;
     if (d.jbase >= d.nchunk) {
         d.n++;
         d.jbase = 0;
-        phase_load_plane(d, planes, nmax, rate_only);
+        phase_load_plane<QS>(d, planes, nmax, rate_only);
     }
     return d;
 }
@@ -606,21 +609,21 @@ __device__ __forceinline__ PhaseDesc phase_next(PhaseDesc d, const PlaneInfo *pl
 // list A (rate-producing) followed by list B -- are ONE sequence cut into 64-cell chunks, taken from the last
 // chunk down; the chunk that straddles the two lists counts as rate-producing (its B lanes never fire).
 // rates: wave-uniform, the chunk holds cells of list A; isA: this lane's cell is one of them.
-template <int NW>
+template <int NW, int QS>
 __device__ __forceinline__ uint32_t slot_index(const PhaseDesc &d, int wave, int q, int lane, bool &valid, bool &isA,
                                                bool &rates) {
     const int jj = d.jbase + wave + q * NW;  // wave-uniform
     const int c = d.nchunk - 1 - jj;
-    const int i = c * 64 + lane;
+    const int i = (c * 64 + lane) >> QS;  // (the low QS bits of the lane number select the quadrant)
     rates = c < d.nchunkA;
     isA = i < d.cntA;
     valid = d.valid && (jj < d.nchunk) && (i < d.cntT);
     return (uint32_t)(valid ? i : 0);
 }
-template <int NW>
+template <int NW, int QS>
 __device__ __forceinline__ uint32_t slot_index(const PhaseDesc &d, int wave, int q, int lane, bool &valid, bool &isA) {
     bool rates;
-    return slot_index<NW>(d, wave, q, lane, valid, isA, rates);
+    return slot_index<NW, QS>(d, wave, q, lane, valid, isA, rates);
 }
 
 // The sweep is latency-bound (rocprofv3: waves wait 73 % of their cycles; an ablation without the
@@ -646,10 +649,17 @@ __device__ __forceinline__ void phase_barrier() {
 
 // THREADS: 256 (one wave per SIMD and workgroup, 4 workgroups per CU) or 1024 (ONE workgroup per CU that may use the
 // whole LDS: same 16 waves per CU, staging arrays up to ~150 KB)
-template <bool LDS_STAGE, bool HEAT, int THREADS, bool WSTAGED>
+// QUAD: one workgroup per (source, pyramid) instead of per (source, sector): the four sign quadrants of a pyramid
+// share the plane structure (same geometry variant -- checked on the host -- same cell lists), so lane l works on
+// quadrant l & 3 of cell (chunk * 64 + l) >> 2.  Planes hold four times the cells, which is what small radii
+// lack: their planes fill a fraction of a wavefront.  Per-quadrant: staging array, sign of the in-plane
+// directions (two sets of row / column tables), ownership mask.  Same arithmetic per cell: bit-identical.
+template <bool LDS_STAGE, bool HEAT, int THREADS, bool WSTAGED, bool QUAD = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(ASORA_WAVES_PER_EU, ASORA_WAVES_PER_EU)))
 void sweep_tab_kernel(SweepArgs A) {
     constexpr int P = ASORA_PHASE_CHUNKS, NW = THREADS / 64;
+    constexpr int QS = QUAD ? 2 : 0, NQ = 1 << QS, NS = QUAD ? 2 : 1;  // quadrants per wave, sign sets per table
+    static_assert(!QUAD || LDS_STAGE, "the four-quadrant kernel stages in LDS");
     const double max_coldensh = (double)2e30f;  // raytracing.f90:368
     static_assert(LDS_STAGE || WSTAGED, "column-density-only staging is an LDS layout");
     PlaneCtx<LDS_STAGE, WSTAGED> C;
@@ -660,25 +670,31 @@ void sweep_tab_kernel(SweepArgs A) {
     const uint32_t N2 = (uint32_t)N * (uint32_t)N;
     // LDS (in doubles): [cw pairs: 2*E, or column densities: E rounded up to even (LDS staging only)] [du: 2W] [dv: 2W] [rowU, colV: W ints each] [log10 table]
     const int E = A.cw_entries, W = A.wtab;
-    const int off_du = LDS_STAGE ? (WSTAGED ? 2 * E : (E + 1) & ~1) : 0;
+    const int SW = NS * W;  // entries per row / column table (QUAD: the +1 direction set, then the -1 set)
+    const int off_du = LDS_STAGE ? NQ * (WSTAGED ? 2 * E : (E + 1) & ~1) : 0;
     double2 *const du_tab = reinterpret_cast<double2 *>(asora_smem + off_du);
-    double2 *const dv_tab = du_tab + W;
-    int *const rowU = reinterpret_cast<int *>(asora_smem + off_du + 4 * W);
-    int *const colV = rowU + W;
+    double2 *const dv_tab = du_tab + SW;
+    int *const rowU = reinterpret_cast<int *>(asora_smem + off_du + 4 * SW);
+    int *const colV = rowU + SW;
     // the variant's plane table: read through LDS so that stepping to the next plane never touches vmcnt
-    PlaneInfo *const planes = reinterpret_cast<PlaneInfo *>(asora_smem + off_du + 5 * W + (W & 1));
+    PlaneInfo *const planes = reinterpret_cast<PlaneInfo *>(asora_smem + off_du + 5 * SW + (SW & 1));
     C.stg.g = LDS_STAGE ? nullptr : reinterpret_cast<double2 *>(A.gscratch) + (size_t)blockIdx.x * (size_t)E;
-    C.lg = load_log10_table(A.log10_table, off_du + 5 * W + (W & 1) + PLANE_INFO_DOUBLES * A.nplanes, tid, THREADS);
+    C.lg = load_log10_table(A.log10_table, off_du + 5 * SW + (SW & 1) + PLANE_INFO_DOUBLES * A.nplanes, tid, THREADS);
+    // this lane's quadrant: staging array, sign sets
+    const int quad = QUAD ? (lane & 3) : 0;
+    const uint32_t stg_q = (uint32_t)(quad * E);
+    const uint32_t set_u = QUAD ? (uint32_t)((quad >> 1) * W) : 0u, set_v = QUAD ? (uint32_t)((quad & 1) * W) : 0u;
     const double w_empty = weightf(0.0, A.sig);  // weight of a guard / never-written entry
 
     for (long long task = blockIdx.x; task < A.ntasks; task += gridDim.x) {
-        const int s = (int)(task / SECTORS);
-        const int t = (int)(task - (long long)s * SECTORS);
+        constexpr int TASKS_PER_SOURCE = SECTORS / NQ;
+        const int s = (int)(task / TASKS_PER_SOURCE);
+        const int t = (int)(task - (long long)s * TASKS_PER_SOURCE) * NQ;  // first sector of this task
         const int src = A.src_begin + s;
         const int axis = t >> 3;  // 0: z-dominant, 1: y-dominant, 2: x-dominant
         const int sp = (t & 4) ? -1 : 1;
-        const int su = (t & 2) ? -1 : 1;
-        const int sv = (t & 1) ? -1 : 1;
+        const int su = QUAD ? ((quad & 2) ? -1 : 1) : ((t & 2) ? -1 : 1);  // QUAD: per lane
+        const int sv = QUAD ? ((quad & 1) ? -1 : 1) : ((t & 1) ? -1 : 1);
         const int i0 = A.src_pos[3 * src + 0], j0 = A.src_pos[3 * src + 1], k0 = A.src_pos[3 * src + 2];
         int p0, u0, v0;
         if (axis == 0) { p0 = k0; u0 = i0; v0 = j0; }
@@ -700,7 +716,9 @@ void sweep_tab_kernel(SweepArgs A) {
         const int nmax = min(min(sp > 0 ? A.last_r : A.last_l, A.q_max), rate_only ? A.nmax_rate : 0x7fffffff);
         const uint32_t strideP = (axis == 2) ? N2 : (uint32_t)N;
         const uint32_t strideU = (axis == 2) ? (uint32_t)N : N2;
-        const int variant = A.vmap[(((su < 0) ? 2 : 0) + ((sv < 0) ? 1 : 0)) * 2 + (axis != 0 ? 1 : 0)];
+        // (QUAD: the host has checked that the four quadrants share their variant)
+        const int variant = QUAD ? A.vmap[axis != 0 ? 1 : 0]
+                                 : A.vmap[(((su < 0) ? 2 : 0) + ((sv < 0) ? 1 : 0)) * 2 + (axis != 0 ? 1 : 0)];
         // (the previous task's last barrier guarantees nobody still reads the plane table)
         for (int i = tid; i < A.nplanes; i += THREADS) planes[i] = A.planes[(size_t)variant * A.nplanes + i];
         __syncthreads();
@@ -709,37 +727,42 @@ void sweep_tab_kernel(SweepArgs A) {
         // phase descriptors of p and p+1, cell coordinates of p
         PhaseDesc d0, d1;
         d0.n = 1; d0.jbase = 0; d0.off = 0; d0.cntA = d0.cntT = d0.nchunkA = d0.nchunk = 0;
-        phase_load_plane(d0, planes, nmax, rate_only);
-        d1 = phase_next<NW * P>(d0, planes, nmax, rate_only);
+        phase_load_plane<QS>(d0, planes, nmax, rate_only);
+        d1 = phase_next<NW * P, QS>(d0, planes, nmax, rate_only);
         uint2 meta_c[P], meta_n[P];
 #pragma unroll
         for (int q = 0; q < P; q++) {
             bool v, ia;
-            meta_c[q] = at_byte(A.cell_meta, (d0.off + slot_index<NW>(d0, wave, q, lane, v, ia)) * 8u);
+            meta_c[q] = at_byte(A.cell_meta, (d0.off + slot_index<NW, QS>(d0, wave, q, lane, v, ia)) * 8u);
         }
 
         // (the previous task's last barrier guarantees nobody still reads the arrays below)
-        for (int i = tid; i < E; i += THREADS) C.stg.st((uint32_t)i, 0.0, w_empty);
-        for (int i = tid; i < W; i += THREADS) {
-            rowU[i] = (int)((uint32_t)wrap(u0 + su * i, N) * strideU);
-            colV[i] = wrap(v0 + sv * i, N);
+        // entry i of a row / column table: offset i % W in direction +1 (first set) or, QUAD only, -1 (second set);
+        // without QUAD the single set has the task's direction
+        auto table_dir = [&](int i, int s_task) { return QUAD ? (i >= W ? -1 : 1) : s_task; };
+        for (int i = tid; i < NQ * E; i += THREADS) C.stg.st((uint32_t)i, 0.0, w_empty);
+        for (int i = tid; i < SW; i += THREADS) {
+            const int o = i >= W ? i - W : i;
+            rowU[i] = (int)((uint32_t)wrap(u0 + table_dir(i, su) * o, N) * strideU);
+            colV[i] = wrap(v0 + table_dir(i, sv) * o, N);
         }
         {
             const double alam = planes[1].alam;
-            for (int i = tid; i < 2 * W; i += THREADS) {
-                if (i < W) du_tab[i] = interp_offsets(i, su, u0 + 1, alam);
-                else dv_tab[i - W] = interp_offsets(i - W, sv, v0 + 1, alam);
+            for (int i = tid; i < 2 * SW; i += THREADS) {
+                const int j = i < SW ? i : i - SW, o = j >= W ? j - W : j;
+                if (i < SW) du_tab[j] = interp_offsets(o, table_dir(j, su), u0 + 1, alam);
+                else dv_tab[j] = interp_offsets(o, table_dir(j, sv), v0 + 1, alam);
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            // source cell, raytracing.f90:430-439
+        if (tid < NQ) {
+            // source cell, raytracing.f90:430-439 (QUAD: one copy per quadrant's staging array)
             const uint32_t g0 = (uint32_t)p0 * strideP + (uint32_t)u0 * strideU + (uint32_t)v0;
             double nHI = nhi[g0];
             double path = 0.5 * A.dr;
             double cdo = 0.0 + nHI * path;
-            C.stg.st(pos00, cdo, weightf(cdo, A.sig));
-            if (t == 0) {
+            C.stg.st(pos00 + stg_q, cdo, weightf(cdo, A.sig));
+            if (t == 0 && tid == 0) {
                 double vol_ph = A.dr * A.dr * A.dr;
                 double ph, ht = 0.0;
                 cell_rates<HEAT>(A, C.lg, flux, 0.0, cdo, vol_ph, nHI, ph, ht);
@@ -759,9 +782,9 @@ void sweep_tab_kernel(SweepArgs A) {
 #pragma unroll
             for (int q = 0; q < P; q++) {
                 bool v, ia;
-                const uint32_t idx = slot_index<NW>(d0, wave, q, lane, v, ia);
+                const uint32_t idx = slot_index<NW, QS>(d0, wave, q, lane, v, ia);
                 const uint32_t a = meta_c[q].x & META_COORD_MASK, b = (meta_c[q].x >> META_COORD_BITS) & META_COORD_MASK;
-                g_c[q] = baseP + (uint32_t)rowU[a] + (uint32_t)colV[b];
+                g_c[q] = baseP + (uint32_t)rowU[set_u + a] + (uint32_t)colV[set_v + b];
                 geo_c[q] = at_byte(A.cell_geo, (d0.off + idx) * 16u);
                 nhi_c[q] = at_byte(nhi, g_c[q] * 8u);
             }
@@ -775,7 +798,7 @@ void sweep_tab_kernel(SweepArgs A) {
 #pragma unroll
             for (int q = 0; q < P; q++) {
                 bool v, ia;
-                idx_n[q] = d1.off + slot_index<NW>(d1, wave, q, lane, v, ia);
+                idx_n[q] = d1.off + slot_index<NW, QS>(d1, wave, q, lane, v, ia);
                 meta_n[q] = at_byte(A.cell_meta, idx_n[q] * 8u);
             }
 
@@ -787,11 +810,11 @@ void sweep_tab_kernel(SweepArgs A) {
             // one slot: 4-point interpolation, new column density and its weight (raytracing.f90:662-813)
             auto interp = [&](const int q, const bool plane1, const bool with_cdh) __attribute__((always_inline)) {
                 bool valid, isA, rates;
-                (void)slot_index<NW>(d0, wave, q, lane, valid, isA, rates);
+                (void)slot_index<NW, QS>(d0, wave, q, lane, valid, isA, rates);
                 const uint2 m = meta_c[q];
                 const uint32_t a = m.x & META_COORD_MASK, b = (m.x >> META_COORD_BITS) & META_COORD_MASK;
-                const double2 du = du_tab[a], dv = dv_tab[b];
-                const uint32_t o_up = m.y & 0xffffu, o_cur = m.y >> 16;
+                const double2 du = du_tab[set_u + a], dv = dv_tab[set_v + b];
+                const uint32_t o_up = (m.y & 0xffffu) + stg_q, o_cur = (m.y >> 16) + stg_q;
                 const double2 e1 = C.stg.ld(o_up);       // (a-1, b-1)
                 const double2 e3 = C.stg.ld(o_up + 1);   // (a-1, b)
                 const double2 e2 = C.stg.ld(o_cur);      // (a,   b-1)
@@ -868,7 +891,7 @@ void sweep_tab_kernel(SweepArgs A) {
 #pragma unroll
                 for (int q = 0; q < P; q++) {
                     const uint32_t a = meta_n[q].x & META_COORD_MASK, b = (meta_n[q].x >> META_COORD_BITS) & META_COORD_MASK;
-                    g_n[q] = baseP + (uint32_t)rowU[a] + (uint32_t)colV[b];
+                    g_n[q] = baseP + (uint32_t)rowU[set_u + a] + (uint32_t)colV[set_v + b];
                     geo_n[q] = at_byte(A.cell_geo, idx_n[q] * 16u);
                     nhi_n[q] = at_byte(nhi, g_n[q] * 8u);
                 }
@@ -920,15 +943,16 @@ void sweep_tab_kernel(SweepArgs A) {
                 if (woff[q] >= 0) C.stg.st((uint32_t)woff[q], cdo[q], wo[q]);
             if (d1.n != n) {  // last phase of this plane: interpolation offsets of the next one
                 const double alam_next = planes[min(n + 1, A.nplanes - 1)].alam;
-                for (int i = tid; i < 2 * W; i += THREADS) {
-                    if (i < W) du_tab[i] = interp_offsets(i, su, u0 + 1, alam_next);
-                    else dv_tab[i - W] = interp_offsets(i - W, sv, v0 + 1, alam_next);
+                for (int i = tid; i < 2 * SW; i += THREADS) {
+                    const int j = i < SW ? i : i - SW, o = j >= W ? j - W : j;
+                    if (i < SW) du_tab[j] = interp_offsets(o, table_dir(j, su), u0 + 1, alam_next);
+                    else dv_tab[j] = interp_offsets(o, table_dir(j, sv), v0 + 1, alam_next);
                 }
             }
             phase_barrier<LDS_STAGE>();  // new values visible
             // ---- rotate the pipeline --------------------------------------------------------------
             d0 = d1;
-            d1 = phase_next<NW * P>(d1, planes, nmax, rate_only);
+            d1 = phase_next<NW * P, QS>(d1, planes, nmax, rate_only);
 #pragma unroll
             for (int q = 0; q < P; q++) {
                 meta_c[q] = meta_n[q];

@@ -19,7 +19,9 @@ def asora():
 MESHES = [4, 5, 7, 8, 12, 17, 24, 31, 40]
 VARIANTS = [dict(), dict(wg_threads=64), dict(wg_threads=128), dict(wg_threads=192), dict(wg_threads=512),
             dict(wg_threads=1024), dict(wg_threads=1024, compact_staging=1), dict(wg_threads=256, compact_staging=1),
-            dict(force_generic=1), dict(source_order=0), dict(skip_unobserved=1), dict(lds_stage_limit=1024)]
+            dict(force_generic=1), dict(source_order=0), dict(skip_unobserved=1), dict(lds_stage_limit=1024),
+            dict(quad_kernel=-1), dict(quad_kernel=1), dict(quad_kernel=1, wg_threads=64), dict(quad_kernel=1, wg_threads=256, compact_staging=1),
+            dict(quad_kernel=1, skip_unobserved=1)]
 
 
 @pytest.mark.parametrize("seed", range(96))
@@ -42,7 +44,7 @@ def test_random_small_case_vs_oracle(asora, port_oracle, seed):
         phi, cdh, heat = run_hip(asora, c, heat=with_heat)
     finally:
         for k in opts:
-            asora.set_option(k, 2 if k == "source_order" else 0)
+            asora.set_option(k, {"source_order": 2}.get(k, 0))
     o = cases.run_oracle(port_oracle, c, heat=with_heat, sens=True)
     r = compare(phi, o["phi_ion"], sens=o["phi_sens"])
     assert r["ok"] and r["support_equal"], (N, R, ns, opts, r)

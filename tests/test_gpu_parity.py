@@ -282,6 +282,40 @@ def test_heat_output_of_the_kernel_variants(asora, golden_dir, opts):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("opts", [dict(wg_threads=64), dict(wg_threads=128), dict(wg_threads=256),
+                                  dict(wg_threads=128, compact_staging=1), dict()])
+@pytest.mark.parametrize("name", ["rcut7p3", "multi16_equal", "multi16_unequal"])
+def test_four_quadrant_kernel_equals_sector_kernel(asora, golden_dir, name, opts):
+    """The four-quadrant variant (one workgroup per source and pyramid, lane l on quadrant l & 3; picked for small
+    radii) does the same arithmetic per cell: single source -> bit-identical phi, heat and coldensh_out; all
+    sources -> the same sum."""
+    c = load_golden(golden_dir, name)
+    heat = bool(c["heat_valid"])
+    asora.set_option("quad_kernel", -1)
+    try:
+        ref = run_hip(asora, c, heat=heat, num_src=1)
+        assert not asora.last_launch_info()["quad"]
+        ref_all = run_hip(asora, c)
+    finally:
+        asora.set_option("quad_kernel", 0)
+    asora.set_option("quad_kernel", 1)
+    for k, v in opts.items():
+        asora.set_option(k, v)
+    try:
+        out = run_hip(asora, c, heat=heat, num_src=1)
+        info = asora.last_launch_info()
+        assert info["quad"] and info["table_driven"] and info["staging"].startswith("lds"), info
+        out_all = run_hip(asora, c)
+    finally:
+        asora.set_option("quad_kernel", 0)
+        for k in opts:
+            asora.set_option(k, 0)
+    for a, b in zip(out, ref):
+        assert (a is None and b is None) or np.array_equal(a, b)
+    assert np.array_equal(out_all[1], ref_all[1])
+    assert np.allclose(out_all[0], ref_all[0], rtol=1e-13, atol=0)
+
+
 @pytest.mark.parametrize("name", ["multi16_unequal", "rcut7p3", "lognormal48", "corner33"])
 def test_skip_unobserved_cells(asora, golden_dir, name):
     """Option skip_unobserved (off by default; never used by bench.py): cells outside the R-sphere are not
