@@ -140,7 +140,7 @@ int asora_last_sweep_ms(float *ms);
 
 /* Launch geometry of the last sweep (for profile matching): workgroups, threads per workgroup, dynamic LDS
  * bytes per workgroup, and where the staged column densities lived: 0 global scratch, 1 LDS as (column
- * density, weight) pairs, 2 LDS as column densities only; +4 when the four-quadrant kernel ran. */
+ * density, weight) pairs, 2 LDS as column densities only; +4 * log2(sectors per workgroup) when the four-quadrant / eight-octant kernel ran. */
 int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_is_lds);
 
 /* Tuning / test switches: "force_generic" (1: always run the table-free sweep kernel),
@@ -153,7 +153,8 @@ int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_i
  * of LDS per entry; 0 = automatic: when the pairs would allow at most one workgroup per CU; -1: never),
  * "quad_kernel" (four sign quadrants of a pyramid per workgroup, for small radii; 0 = automatic: up to
  * "quad_max_entries" staged entries per quadrant, default 1100, i.e. R <~ 41 cells; 1: whenever the quadrants share
- * their geometry; -1: never),
+ * their geometry; 2: eight octants of an axis per workgroup, automatic up to "oct_max_entries", default 64, R <~ 8;
+ * -1: never),
  * "source_order" (see asora_source_order),
  * "skip_unobserved" (1: cells outside the R-sphere -- never upwind of a cell inside it -- are swept only for
  * the source whose column density is exported; phi and coldensh_out unchanged, ~27 % less time at 256^3 / R = 60;

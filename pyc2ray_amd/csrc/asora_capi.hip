@@ -77,6 +77,7 @@ struct State {
     int lds_pad = 0;              // option "lds_pad": extra dynamic LDS per workgroup (occupancy experiments)
     int wg_threads = 0;           // option "wg_threads": workgroup size of the table-driven kernel, 256/512/1024 (0: automatic)
     int quad_kernel = 0;          // option "quad_kernel": four quadrants per workgroup (0: automatic, 1: whenever possible, -1: never)
+    int oct_max_entries = 64;     // option "oct_max_entries": automatic choice of eight octants per workgroup up to this many entries (R <~ 8)
     int quad_max_entries = 1100;  // option "quad_max_entries": automatic choice up to this many staged entries per quadrant (R <~ 41)
     int last_quad = 0;
     int compact_staging = 0;      // option "compact_staging": stage column densities only (0: automatic, 1: always, -1: never)
@@ -281,7 +282,7 @@ int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
     return 0;
 }
 
-template <bool L, bool H, int T, bool WS = true, bool QD = false>
+template <bool L, bool H, int T, bool WS = true, int QD = 0>
 int launch_sweep_tab(const asora::SweepArgs &A, int grid, size_t lds, hipStream_t st) {
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)asora::sweep_tab_kernel<L, H, T, WS, QD>,
@@ -451,21 +452,26 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     }
     size_t lds_stage, lds_stage_c = 0, lds_fixed;
     bool quad = false;
+    int qshift = 0;
     if (use_tab) {
         // ONE packed array of (column density, weight) pairs, updated in place, + per-row/column tables
         A.planes = S.planes_dev; A.cell_meta = S.cell_meta_dev; A.cell_geo = S.cell_geo_dev;
         A.nplanes = S.geo_nplanes; A.cw_entries = S.geo_entries;
         A.rate_only = S.skip_unobserved ? 1 : 0; A.nmax_rate = S.geo_nmax_rate;
         for (int i = 0; i < 8; i++) A.vmap[i] = S.geo_vmap[i];
-        // four-quadrant kernel (small radii): the quadrants of a pyramid must share their geometry variant, and four
-        // staging arrays must fit in LDS
+        // four-quadrant / eight-octant kernel (small radii): the sectors a workgroup takes side by side must share
+        // their geometry variant (and, for the octants, their planes), and their staging arrays must fit in LDS
         quad = S.quad_kernel >= 0 && num_src > 0 && S.lds_stage_limit <= 0;
         for (int i = 2; i < 8; i++) quad = quad && S.geo_vmap[i] == S.geo_vmap[i & 1];
         if (quad && S.quad_kernel == 0)  // automatic: small radii, and no workgroup size forced that the variant lacks
             quad = A.cw_entries <= S.quad_max_entries &&
                    (S.wg_threads == 0 || S.wg_threads == 64 || S.wg_threads == 128 || S.wg_threads == 256);
-        for (int pass = 0; pass < 2; pass++) {
-            const size_t nq = quad ? 4 : 1, sw = (size_t)(quad ? 2 : 1) * A.wtab;
+        qshift = quad ? 2 : 0;
+        if (quad && A.q_max <= std::min(A.last_l, A.last_r) &&
+            (S.quad_kernel == 2 || (S.quad_kernel == 0 && A.cw_entries <= S.oct_max_entries)))
+            qshift = 3;
+        for (;;) {
+            const size_t nq = (size_t)1 << qshift, sw = (size_t)(quad ? 2 : 1) * A.wtab;
             lds_stage = nq * (size_t)A.cw_entries * 2 * sizeof(double);
             lds_stage_c = nq * (size_t)((A.cw_entries + 1) & ~1) * sizeof(double);  // column densities only
             lds_fixed = (size_t)(5 * sw + (sw & 1) + asora::PLANE_INFO_DOUBLES * A.nplanes) * sizeof(double) + lds_log;
@@ -473,10 +479,11 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
                                  (size_t)S.lds_pad <= (size_t)S.max_lds)
                 break;
             if (S.quad_kernel > 0)
-                return fail(13, "asora_do_all_sources: the four-quadrant kernel does not fit in LDS at this radius");
-            quad = false;
+                return fail(13, "asora_do_all_sources: the multi-sector kernel does not fit in LDS at this radius");
+            if (qshift == 3) qshift = 2;
+            else { quad = false; qshift = 0; }
         }
-        if (quad) A.ntasks = (long long)(asora::SECTORS / 4) * num_src;
+        if (quad) A.ntasks = (long long)(asora::SECTORS >> qshift) * num_src;
     } else {
         lds_stage = 2 * (size_t)A.plane_elems * sizeof(double);  // table-free kernel: two square planes
         lds_fixed = lds_log;
@@ -561,14 +568,17 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             constexpr int T = asora::SWEEP_THREADS;
 #define ASORA_LAUNCH_TAB(L, TH, WS) \
     (want_heat ? launch_sweep_tab<L, true, TH, WS>(A, grid, lds, st) : launch_sweep_tab<L, false, TH, WS>(A, grid, lds, st))
-#define ASORA_LAUNCH_QUAD(TH, WS) \
-    (want_heat ? launch_sweep_tab<true, true, TH, WS, true>(A, grid, lds, st) \
-               : launch_sweep_tab<true, false, TH, WS, true>(A, grid, lds, st))
+#define ASORA_LAUNCH_QUAD(TH, WS, QD) \
+    (want_heat ? launch_sweep_tab<true, true, TH, WS, QD>(A, grid, lds, st) \
+               : launch_sweep_tab<true, false, TH, WS, QD>(A, grid, lds, st))
+#define ASORA_LAUNCH_QUAD_T(TH) \
+    (qshift == 3 ? (compact ? ASORA_LAUNCH_QUAD(TH, false, 3) : ASORA_LAUNCH_QUAD(TH, true, 3)) \
+                 : (compact ? ASORA_LAUNCH_QUAD(TH, false, 2) : ASORA_LAUNCH_QUAD(TH, true, 2)))
             if (quad) {
-                if (threads == 64) rc = compact ? ASORA_LAUNCH_QUAD(64, false) : ASORA_LAUNCH_QUAD(64, true);
-                else if (threads == 128) rc = compact ? ASORA_LAUNCH_QUAD(128, false) : ASORA_LAUNCH_QUAD(128, true);
-                else if (threads == 256) rc = compact ? ASORA_LAUNCH_QUAD(256, false) : ASORA_LAUNCH_QUAD(256, true);
-                else return fail(13, "asora_do_all_sources: the four-quadrant kernel runs 64, 128 or 256 threads");
+                if (threads == 64) rc = ASORA_LAUNCH_QUAD_T(64);
+                else if (threads == 128) rc = ASORA_LAUNCH_QUAD_T(128);
+                else if (threads == 256) rc = ASORA_LAUNCH_QUAD_T(256);
+                else return fail(13, "asora_do_all_sources: the multi-sector kernel runs 64, 128 or 256 threads");
             } else if (compact) {
                 if (threads == 1024) rc = ASORA_LAUNCH_TAB(true, 1024, false);
                 else if (threads == 512) rc = ASORA_LAUNCH_TAB(true, 512, false);
@@ -582,6 +592,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             else rc = ASORA_LAUNCH_TAB(false, T, true);
 #undef ASORA_LAUNCH_TAB
 #undef ASORA_LAUNCH_QUAD
+#undef ASORA_LAUNCH_QUAD_T
         } else {
             if (use_lds) rc = want_heat ? launch_sweep<true, true>(A, grid, lds, st) : launch_sweep<true, false>(A, grid, lds, st);
             else rc = want_heat ? launch_sweep<false, true>(A, grid, lds, st) : launch_sweep<false, false>(A, grid, lds, st);
@@ -590,7 +601,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         HIP_TRY(hipEventRecord(S.ev1, st));
         S.timed = true;
         S.last_grid = grid; S.last_block = use_tab ? threads : asora::SWEEP_THREADS; S.last_lds = (int)lds;
-        S.last_is_lds = (use_lds ? (compact ? 2 : 1) : 0) | (quad ? 4 : 0);
+        S.last_is_lds = (use_lds ? (compact ? 2 : 1) : 0) | (qshift << 2);
     }
 
     hipLaunchKernelGGL(asora::finalize_kernel, tg, tb, 0, st, S.phiA, S.phiB, phi_out_dev, N);
@@ -694,7 +705,7 @@ int asora_device_close(void) {
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     State fresh;  // options and the last launch record survive a close
-    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.compact_staging = S.compact_staging; fresh.quad_kernel = S.quad_kernel; fresh.quad_max_entries = S.quad_max_entries; fresh.last_quad = S.last_quad; fresh.max_table_cells = S.max_table_cells;
+    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.compact_staging = S.compact_staging; fresh.quad_kernel = S.quad_kernel; fresh.quad_max_entries = S.quad_max_entries; fresh.oct_max_entries = S.oct_max_entries; fresh.last_quad = S.last_quad; fresh.max_table_cells = S.max_table_cells;
     fresh.last_tab = S.last_tab; fresh.last_grid = S.last_grid; fresh.last_block = S.last_block;
     fresh.last_lds = S.last_lds; fresh.last_is_lds = S.last_is_lds;
     S = fresh;
@@ -956,6 +967,7 @@ int asora_set_option(const char *name, long long value) {
     else if (!std::strcmp(name, "source_order")) S.source_order = (int)value;
     else if (!std::strcmp(name, "quad_kernel")) S.quad_kernel = (int)value;
     else if (!std::strcmp(name, "quad_max_entries")) S.quad_max_entries = (int)value;
+    else if (!std::strcmp(name, "oct_max_entries")) S.oct_max_entries = (int)value;
     else if (!std::strcmp(name, "compact_staging")) S.compact_staging = (int)value;
     else if (!std::strcmp(name, "skip_unobserved")) S.skip_unobserved = value != 0;
     else return fail(12, "asora_set_option: unknown option '%s'", name);

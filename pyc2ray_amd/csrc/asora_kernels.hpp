@@ -654,11 +654,15 @@ __device__ __forceinline__ void phase_barrier() {
 // quadrant l & 3 of cell (chunk * 64 + l) >> 2.  Planes hold four times the cells, which is what small radii
 // lack: their planes fill a fraction of a wavefront.  Per-quadrant: staging array, sign of the in-plane
 // directions (two sets of row / column tables), ownership mask.  Same arithmetic per cell: bit-identical.
-template <bool LDS_STAGE, bool HEAT, int THREADS, bool WSTAGED, bool QUAD = false>
+// QSHIFT = 3: the same with all eight sign octants of an axis (both pyramids) per workgroup, for the smallest radii;
+// requires that the box limits bind on neither side (host check), so that both pyramids have the same planes.
+template <bool LDS_STAGE, bool HEAT, int THREADS, bool WSTAGED, int QSHIFT = 0>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(ASORA_WAVES_PER_EU, ASORA_WAVES_PER_EU)))
 void sweep_tab_kernel(SweepArgs A) {
     constexpr int P = ASORA_PHASE_CHUNKS, NW = THREADS / 64;
-    constexpr int QS = QUAD ? 2 : 0, NQ = 1 << QS, NS = QUAD ? 2 : 1;  // quadrants per wave, sign sets per table
+    constexpr bool QUAD = QSHIFT != 0, OCT = QSHIFT == 3;
+    static_assert(QSHIFT == 0 || QSHIFT == 2 || QSHIFT == 3, "1, 4 or 8 sectors per workgroup");
+    constexpr int QS = QSHIFT, NQ = 1 << QS, NS = QUAD ? 2 : 1;  // sectors per wave, sign sets per table
     static_assert(!QUAD || LDS_STAGE, "the four-quadrant kernel stages in LDS");
     const double max_coldensh = (double)2e30f;  // raytracing.f90:368
     static_assert(LDS_STAGE || WSTAGED, "column-density-only staging is an LDS layout");
@@ -681,9 +685,9 @@ void sweep_tab_kernel(SweepArgs A) {
     C.stg.g = LDS_STAGE ? nullptr : reinterpret_cast<double2 *>(A.gscratch) + (size_t)blockIdx.x * (size_t)E;
     C.lg = load_log10_table(A.log10_table, off_du + 5 * SW + (SW & 1) + PLANE_INFO_DOUBLES * A.nplanes, tid, THREADS);
     // this lane's quadrant: staging array, sign sets
-    const int quad = QUAD ? (lane & 3) : 0;
+    const int quad = QUAD ? (lane & (NQ - 1)) : 0;
     const uint32_t stg_q = (uint32_t)(quad * E);
-    const uint32_t set_u = QUAD ? (uint32_t)((quad >> 1) * W) : 0u, set_v = QUAD ? (uint32_t)((quad & 1) * W) : 0u;
+    const uint32_t set_u = QUAD ? (uint32_t)(((quad >> 1) & 1) * W) : 0u, set_v = QUAD ? (uint32_t)((quad & 1) * W) : 0u;
     const double w_empty = weightf(0.0, A.sig);  // weight of a guard / never-written entry
 
     for (long long task = blockIdx.x; task < A.ntasks; task += gridDim.x) {
@@ -692,7 +696,7 @@ void sweep_tab_kernel(SweepArgs A) {
         const int t = (int)(task - (long long)s * TASKS_PER_SOURCE) * NQ;  // first sector of this task
         const int src = A.src_begin + s;
         const int axis = t >> 3;  // 0: z-dominant, 1: y-dominant, 2: x-dominant
-        const int sp = (t & 4) ? -1 : 1;
+        const int sp = OCT ? ((quad & 4) ? -1 : 1) : ((t & 4) ? -1 : 1);  // OCT: per lane
         const int su = QUAD ? ((quad & 2) ? -1 : 1) : ((t & 2) ? -1 : 1);  // QUAD: per lane
         const int sv = QUAD ? ((quad & 1) ? -1 : 1) : ((t & 1) ? -1 : 1);
         const int i0 = A.src_pos[3 * src + 0], j0 = A.src_pos[3 * src + 1], k0 = A.src_pos[3 * src + 2];
@@ -713,7 +717,9 @@ void sweep_tab_kernel(SweepArgs A) {
         // Cells outside the R-sphere (list B) are never upwind of a cell inside it: they only feed the exported
         // column density.  With "skip_unobserved" every other source sweeps list A only.
         const bool rate_only = A.rate_only && src != A.cdh_src;
-        const int nmax = min(min(sp > 0 ? A.last_r : A.last_l, A.q_max), rate_only ? A.nmax_rate : 0x7fffffff);
+        // (OCT: the host has checked q_max <= min(last_l, last_r): both pyramids march the same planes)
+        const int nmax = min(min(OCT ? min(A.last_r, A.last_l) : (sp > 0 ? A.last_r : A.last_l), A.q_max),
+                             rate_only ? A.nmax_rate : 0x7fffffff);
         const uint32_t strideP = (axis == 2) ? N2 : (uint32_t)N;
         const uint32_t strideU = (axis == 2) ? (uint32_t)N : N2;
         // (QUAD: the host has checked that the four quadrants share their variant)

@@ -21,10 +21,11 @@ VARIANTS = [dict(), dict(wg_threads=64), dict(wg_threads=128), dict(wg_threads=1
             dict(wg_threads=1024), dict(wg_threads=1024, compact_staging=1), dict(wg_threads=256, compact_staging=1),
             dict(force_generic=1), dict(source_order=0), dict(skip_unobserved=1), dict(lds_stage_limit=1024),
             dict(quad_kernel=-1), dict(quad_kernel=1), dict(quad_kernel=1, wg_threads=64), dict(quad_kernel=1, wg_threads=256, compact_staging=1),
-            dict(quad_kernel=1, skip_unobserved=1)]
+            dict(quad_kernel=1, skip_unobserved=1), dict(quad_kernel=2), dict(quad_kernel=2, wg_threads=128),
+            dict(quad_kernel=2, compact_staging=1, skip_unobserved=1)]
 
 
-@pytest.mark.parametrize("seed", range(96))
+@pytest.mark.parametrize("seed", range(120))
 def test_random_small_case_vs_oracle(asora, port_oracle, seed):
     rng = np.random.default_rng(9000 + seed)
     N = MESHES[seed % len(MESHES)]

@@ -283,11 +283,13 @@ def test_heat_output_of_the_kernel_variants(asora, golden_dir, opts):
 
 
 @pytest.mark.parametrize("opts", [dict(wg_threads=64), dict(wg_threads=128), dict(wg_threads=256),
-                                  dict(wg_threads=128, compact_staging=1), dict()])
+                                  dict(wg_threads=128, compact_staging=1), dict(),
+                                  dict(quad_kernel=2), dict(quad_kernel=2, wg_threads=64),
+                                  dict(quad_kernel=2, wg_threads=256, compact_staging=1)])
 @pytest.mark.parametrize("name", ["rcut7p3", "multi16_equal", "multi16_unequal"])
 def test_four_quadrant_kernel_equals_sector_kernel(asora, golden_dir, name, opts):
-    """The four-quadrant variant (one workgroup per source and pyramid, lane l on quadrant l & 3; picked for small
-    radii) does the same arithmetic per cell: single source -> bit-identical phi, heat and coldensh_out; all
+    """The four-quadrant and eight-octant variants (one workgroup per source and pyramid / axis, lane l on sector
+    l & 3 / l & 7; picked for small radii) do the same arithmetic per cell: single source -> bit-identical phi, heat and coldensh_out; all
     sources -> the same sum."""
     c = load_golden(golden_dir, name)
     heat = bool(c["heat_valid"])
@@ -305,6 +307,8 @@ def test_four_quadrant_kernel_equals_sector_kernel(asora, golden_dir, name, opts
         out = run_hip(asora, c, heat=heat, num_src=1)
         info = asora.last_launch_info()
         assert info["quad"] and info["table_driven"] and info["staging"].startswith("lds"), info
+        if name == "rcut7p3":  # (R = 10 at N = 32 reaches the box limits: four quadrants, not eight octants)
+            assert info["sectors_per_workgroup"] == (8 if opts.get("quad_kernel") == 2 else 4), info
         out_all = run_hip(asora, c)
     finally:
         asora.set_option("quad_kernel", 0)
