@@ -152,7 +152,7 @@ int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_i
  * "compact_staging" (1: stage column densities only and recompute the weights, 8 instead of 16 B
  * of LDS per entry; 0 = automatic: when the pairs would allow at most one workgroup per CU; -1: never),
  * "quad_kernel" (four sign quadrants of a pyramid per workgroup, for small radii; 0 = automatic: up to
- * "quad_max_entries" staged entries per quadrant, default 1100, i.e. R <~ 41 cells; 1: whenever the quadrants share
+ * "quad_max_entries" staged entries per quadrant, default 1210, i.e. R <~ 46 cells; 1: whenever the quadrants share
  * their geometry; 2: eight octants of an axis per workgroup, automatic up to "oct_max_entries", default 64, R <~ 8;
  * -1: never),
  * "source_order" (see asora_source_order),

@@ -78,7 +78,7 @@ struct State {
     int wg_threads = 0;           // option "wg_threads": workgroup size of the table-driven kernel, 256/512/1024 (0: automatic)
     int quad_kernel = 0;          // option "quad_kernel": four quadrants per workgroup (0: automatic, 1: whenever possible, -1: never)
     int oct_max_entries = 64;     // option "oct_max_entries": automatic choice of eight octants per workgroup up to this many entries (R <~ 8)
-    int quad_max_entries = 1100;  // option "quad_max_entries": automatic choice up to this many staged entries per quadrant (R <~ 41)
+    int quad_max_entries = 1210;  // option "quad_max_entries": automatic choice up to this many staged entries per quadrant (R <~ 46)
     int last_quad = 0;
     int compact_staging = 0;      // option "compact_staging": stage column densities only (0: automatic, 1: always, -1: never)
     int skip_unobserved = 0;      // option "skip_unobserved": cells outside the R-sphere only for the exported column density
