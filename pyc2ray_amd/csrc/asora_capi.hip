@@ -507,7 +507,11 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     bool compact = false;
     if (use_tab && S.lds_stage_limit <= 0 && S.compact_staging >= 0 &&
         lds_stage_c + lds_fixed + (size_t)S.lds_pad <= (size_t)S.max_lds &&
-        (S.compact_staging > 0 || lds_stage + lds_fixed + (size_t)S.lds_pad > (size_t)S.max_lds / (quad ? 3 : 2))) {
+        (S.compact_staging > 0 || lds_stage + lds_fixed + (size_t)S.lds_pad > (size_t)S.max_lds / (quad ? 3 : 2) ||
+         // two workgroups per CU with pairs, four of 256 threads with column densities only: the latter wins while
+         // it stays below ~33 KB (R = 73: 79.5 -> 76.1 ms per 4000 sources; equal at R = 76; pairs win from R = 80)
+         (!quad && S.wg_threads == 0 && lds_stage + lds_fixed + (size_t)S.lds_pad > (size_t)S.max_lds / 3 &&
+          lds_stage_c + lds_fixed + (size_t)S.lds_pad <= 33 * 1024))) {
         compact = true;
         lds_stage = lds_stage_c;
     }
@@ -533,7 +537,8 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
                 if (quad && (t == 192 || t > 256)) continue;
                 const int waves = std::min(fit, 16 / (t / 64)) * (t / 64);
                 if (waves > best_waves) { best_waves = waves; threads = t; }
-                if (waves >= 14) break;
+                // (256 threads x 3 workgroups beat 512 x 2: R = 64 51.3 vs 57.1 ms, R = 70 65.2 vs 71.8 per 4000 sources)
+                if (waves >= (t >= 256 ? 12 : 14)) break;
             }
             // few sources (single-source tests: 24 tasks): the chip is not full, so larger workgroups put
             // more waves on each sector (128^3 full box, 1 source: 0.40 ms at 256 threads, 0.25 ms at 1024)
