@@ -223,3 +223,23 @@ def run_oracle(oracle, c, heat=True, flux_mode=1, **kw):
                                  heat_thin=c["heat_thin"] if heat else None,
                                  heat_thick=c["heat_thick"] if heat else None, num_tau=c["num_tau"],
                                  flux_mode=flux_mode, **kw)
+
+
+def run_reference(port, ref, c, heat=False, **kw):
+    """What the full-size GPU tests compare against: the COMPILED REFERENCE's rates when oracle/_ref is there
+    (`ref` not None), else the port's; the conditioning term `phi_sens` always comes from the port (the
+    reference has no such output).  With both at hand the port is first held to the reference on this very
+    input: same support, rates <= 1e-12 relative (libm log10 variants only), column density bit-identical."""
+    o = run_oracle(port, c, heat=heat, sens=True, **kw)
+    o["kind"] = "port"
+    if ref is None:
+        return o
+    r = run_oracle(ref, c, heat=heat, **kw)
+    for k in ("phi_ion",) + (("phi_heat",) if heat else ()):
+        m = r[k] != 0
+        assert np.array_equal(o[k] != 0, m), f"port and compiled reference differ in the support of {k}"
+        assert np.max(np.abs(o[k][m] - r[k][m]) / np.abs(r[k][m])) <= 1e-12
+        o[k] = r[k]
+    assert np.array_equal(o["coldensh_out"], r["coldensh_out"])
+    o["kind"] = "reference"
+    return o

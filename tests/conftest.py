@@ -20,5 +20,13 @@ def port_oracle():
 
 
 @pytest.fixture(scope="session")
+def ref_oracle():
+    """The compiled reference Fortran (oracle/_ref/libc2ray_ref.so: built in the container, travels to the GPU
+    box as a built file), or None where it was never built."""
+    from oracle.oracle import REF_SO, RefOracle
+    return RefOracle() if os.path.exists(REF_SO) else None
+
+
+@pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

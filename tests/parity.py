@@ -47,3 +47,22 @@ def compare(got, ref, sens=None, rtol=RTOL, afloor=AFLOOR, ksens=KSENS):
                 support_equal=support_equal, worst=int(np.argmax(rel)) if rel.size else -1,
                 n_sens=int((ok & ~ok_plain).sum()),
                 n_rel_gt=int((rel > rtol).sum()))
+
+
+def record(config, r, **extra):
+    """Append one line {config, max_rel, n_rel_gt, frac_floor, n_sens, support_equal, ...} to the parity report
+    the run leaves behind ($ASORA_PARITY_REPORT, default gpurun_out/parity_report.jsonl at the repo root; the
+    committed copy of a round's GPU run is profiles/rN_parity_report.json)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.environ.get("ASORA_PARITY_REPORT") or os.path.join(root, "gpurun_out", "parity_report.jsonl")
+    line = dict(config=config, **{k: r[k] for k in ("max_rel", "n_rel_gt", "frac_floor", "n_sens", "n_bad",
+                                                    "support_equal", "ok")}, **extra)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(json.dumps(line) + "\n")
+    except OSError:
+        pass  # a read-only tree must not fail a parity test
+    return line

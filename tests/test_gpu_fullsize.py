@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import cases
-from parity import compare
+from parity import compare, record
 from test_gpu_parity import run_hip
 
 pytestmark = pytest.mark.gpu
@@ -19,6 +19,21 @@ def asora():
     return libasora
 
 
+def check_phi(config, phi, o, max_sens=0, max_frac_floor=0.0, max_rel=1e-10):
+    """The bar of every full-size comparison: tests/parity.py's bound, identical support, AND explicit margins --
+    at most `max_sens` cells admitted through the conditioning term, at most `max_frac_floor` of the cells admitted
+    through the absolute floor (1e-14 of the largest rate), worst pure-relative error `max_rel` -- all appended
+    to the parity report (profiles/rN_parity_report.json is the committed copy of the GPU box's run)."""
+    r = compare(phi, o["phi_ion"], sens=o["phi_sens"])
+    line = record(config, r, oracle=o["kind"], bounds=dict(max_sens=max_sens, max_frac_floor=max_frac_floor,
+                                                            max_rel=max_rel))
+    print(f"\n[{config}] vs {o['kind']}: max_rel={r['max_rel']:.3e} n_rel>1e-10={r['n_rel_gt']} n_sens={r['n_sens']} "
+          f"frac_floor={r['frac_floor']:.2e} support_equal={r['support_equal']}")
+    assert r["ok"] and r["support_equal"], line
+    assert r["n_sens"] <= max_sens and r["frac_floor"] <= max_frac_floor and r["max_rel"] <= max_rel, line
+    return r
+
+
 def bench_case(ns, density="uniform", N=256, R=60.0, xh=2e-4):
     """Inputs of bench.py (raytracing_benchmark: cell 3 Mpc / 200, 1e5 K black body, NumTau 20000)."""
     rng = np.random.default_rng(918)
@@ -30,23 +45,20 @@ def bench_case(ns, density="uniform", N=256, R=60.0, xh=2e-4):
 
 
 @pytest.mark.parametrize("density", ["uniform", "clustered"])
-def test_bench_config_vs_oracle(asora, port_oracle, density):
+def test_bench_config_vs_oracle(asora, port_oracle, ref_oracle, density):
     c = bench_case(12, density)
     phi, cdh, _ = run_hip(asora, c)
     info = asora.last_launch_info()
     assert info["table_driven"] and info["staging"] == "lds"
     box = int(np.ceil(c["R"]))
-    o = cases.run_oracle(port_oracle, c, heat=False, sens=True, max_subbox=box, subboxsize=box)
-    r = compare(phi, o["phi_ion"], sens=o["phi_sens"])
-    print(f"\n[bench256 {density}] max_rel={r['max_rel']:.3e} n_rel>1e-10={r['n_rel_gt']} n_sens={r['n_sens']} "
-          f"frac_floor={r['frac_floor']:.2e} support_equal={r['support_equal']}")
-    assert r["ok"] and r["support_equal"], r
+    o = cases.run_reference(port_oracle, ref_oracle, c, max_subbox=box, subboxsize=box)
+    check_phi(f"configs[1] 256^3 {density} R=60, 12 sources", phi, o, **BOUNDS["bench256_" + density])
     # column density of the last source: bit-identical inside the cube the oracle swept
     m = (cdh != 0) & (o["coldensh_out"] != 0)
     assert m.sum() > 1_000_000 and np.array_equal(cdh[m], o["coldensh_out"][m])
 
 
-def test_bench_R100_wide_workgroups_vs_oracle(asora, port_oracle):
+def test_bench_R100_wide_workgroups_vs_oracle(asora, port_oracle, ref_oracle):
     """R = 100 at 256^3: 94 KB of staged (column density, weight) pairs; the library stages the column
     densities only (47 KB; two 512-thread workgroups per CU for long source lists, 1024 threads for the 4
     sources here, which do not fill the chip) instead of global staging."""
@@ -55,16 +67,13 @@ def test_bench_R100_wide_workgroups_vs_oracle(asora, port_oracle):
     info = asora.last_launch_info()
     assert info["table_driven"] and info["staging"] == "lds-compact" and info["block"] == 1024, info
     box = int(np.ceil(c["R"]))
-    o = cases.run_oracle(port_oracle, c, heat=False, sens=True, max_subbox=box, subboxsize=box)
-    r = compare(phi, o["phi_ion"], sens=o["phi_sens"])
-    print(f"\n[bench256 R=100 wide] max_rel={r['max_rel']:.3e} n_rel>1e-10={r['n_rel_gt']} n_sens={r['n_sens']} "
-          f"support_equal={r['support_equal']}")
-    assert r["ok"] and r["support_equal"], r
+    o = cases.run_reference(port_oracle, ref_oracle, c, max_subbox=box, subboxsize=box)
+    check_phi("256^3 clustered R=100 (lds-compact, 1024 threads), 4 sources", phi, o, **BOUNDS["bench256_R100"])
     m = (cdh != 0) & (o["coldensh_out"] != 0)
     assert m.sum() > 4_000_000 and np.array_equal(cdh[m], o["coldensh_out"][m])
 
 
-def test_fullbox_256_single_source_global_staging(asora, port_oracle):
+def test_fullbox_256_single_source_global_staging(asora, port_oracle, ref_oracle):
     """configs[0]-like: one source, uniform 256^3, R beyond the box -> the staged entries no longer fit
     in LDS and live in global memory (the kernel's other staging path)."""
     N = 256
@@ -80,10 +89,8 @@ def test_fullbox_256_single_source_global_staging(asora, port_oracle):
     info = asora.last_launch_info()
     assert info["staging"] == "lds-compact" and info["block"] == 1024, info
     assert np.array_equal(phi_c, phi) and np.array_equal(cdh_c, cdh)
-    o = cases.run_oracle(port_oracle, c, heat=False, sens=True)
-    r = compare(phi, o["phi_ion"], sens=o["phi_sens"])
-    print(f"\n[fullbox256] max_rel={r['max_rel']:.3e} n_sens={r['n_sens']} support_equal={r['support_equal']}")
-    assert r["ok"] and r["support_equal"], r
+    o = cases.run_reference(port_oracle, ref_oracle, c)
+    check_phi("256^3 uniform full box (global staging == lds-compact), 1 source", phi, o, **BOUNDS["fullbox256"])
     assert np.array_equal(cdh, o["coldensh_out"])
 
 
@@ -134,17 +141,16 @@ def test_flux_linearity_and_translation_256(asora):
     assert np.array_equal(phi3 != 0, m) and np.max(np.abs(phi3[m] / ref[m] - 1.0)) <= 1e-8
 
 
-def test_config0_single_source_128_vs_oracle(asora, port_oracle):
+def test_config0_single_source_128_vs_oracle(asora, port_oracle, ref_oracle):
     """BASELINE configs[0] (examples/unit_tests_hackathon/1_single_black_body): one 1e49 s^-1 source at
     1-based (96, 96, 64) in a uniform 128^3 box, black body 5e4 K, R_max = 150 cells (full box)."""
     N = 128
     c = cases._base(N, 150.0, 0.014 * MPC / 128, [[95, 95, 63]], [10.0], xh=np.full((N, N, N), 1.2e-3),
                     table_kw=dict(numtau=10000))
     phi, cdh, _ = run_hip(asora, c)
-    o = cases.run_oracle(port_oracle, c, heat=False, sens=True)
-    r = compare(phi, o["phi_ion"], sens=o["phi_sens"])
-    print(f"\n[config0 128] max_rel={r['max_rel']:.3e} n_sens={r['n_sens']} support_equal={r['support_equal']}")
-    assert r["ok"] and r["support_equal"] and (phi > 0).all(), r
+    o = cases.run_reference(port_oracle, ref_oracle, c)
+    check_phi("configs[0] 128^3 uniform full box, 1 source", phi, o, **BOUNDS["config0"])
+    assert (phi > 0).all()
     assert np.array_equal(cdh, o["coldensh_out"])
 
 
@@ -180,7 +186,7 @@ def run_shards(asora, c, shards):
     return out
 
 
-def test_config3_eor250_sharded(asora, port_oracle):
+def test_config3_eor250_sharded(asora, port_oracle, ref_oracle):
     """BASELINE configs[3] stand-in: N = 250 (even, not a power of two), log-normal density,
     halo-like sources drawn ~ ndens^2 (many share a cell), non-integer R = 58.6.  (i) the first sources
     against the oracle; (ii) the 8-way contiguous shards of pyc2ray/evolve.py:175-186 sum to the
@@ -195,10 +201,8 @@ def test_config3_eor250_sharded(asora, port_oracle):
     c8 = dict(c, pos=pos[:8], flux=flux[:8])
     phi8, _, _ = run_hip(asora, c8)
     box = int(np.ceil(c["R"]))
-    o = cases.run_oracle(port_oracle, c8, heat=False, sens=True, max_subbox=box, subboxsize=box)
-    r = compare(phi8, o["phi_ion"], sens=o["phi_sens"])
-    print(f"\n[eor250 8 sources] max_rel={r['max_rel']:.3e} n_sens={r['n_sens']} frac_floor={r['frac_floor']:.2e}")
-    assert r["ok"] and r["support_equal"], r
+    o = cases.run_reference(port_oracle, ref_oracle, c8, max_subbox=box, subboxsize=box)
+    check_phi("configs[3] 250^3 log-normal R=58.6, 8 halo sources", phi8, o, **BOUNDS["eor250"])
     shards = [shard_sources(ns, rk, 8) for rk in range(8)]
     assert shards[0] == (0, 2000) and shards[-1] == (14000, 16000)
     parts = run_shards(asora, c, [(0, ns)] + shards)
@@ -209,7 +213,7 @@ def test_config3_eor250_sharded(asora, port_oracle):
     assert np.array_equal(summed > 0, m) and rel <= 1e-12
 
 
-def test_config4_stress512(asora, port_oracle):
+def test_config4_stress512(asora, port_oracle, ref_oracle):
     """BASELINE configs[4] stand-in: 512^3 log-normal grid (1 GiB per grid), R = 60: parity on a few sources,
     then a 4000-source call as a capacity / addressing check (positive rates inside the box only)."""
     N = 512
@@ -220,12 +224,76 @@ def test_config4_stress512(asora, port_oracle):
                     table_kw=dict(temp=1e5, numtau=20000))
     c4 = dict(c, pos=pos[:4], flux=flux[:4])
     phi4, cdh4, _ = run_hip(asora, c4)
-    o = cases.run_oracle(port_oracle, c4, heat=False, sens=True, max_subbox=60, subboxsize=60)
-    r = compare(phi4, o["phi_ion"], sens=o["phi_sens"])
-    print(f"\n[stress512 4 sources] max_rel={r['max_rel']:.3e} n_sens={r['n_sens']} frac_floor={r['frac_floor']:.2e}")
-    assert r["ok"] and r["support_equal"], r
+    o = cases.run_reference(port_oracle, ref_oracle, c4, max_subbox=60, subboxsize=60)
+    check_phi("configs[4] 512^3 log-normal R=60, 4 sources", phi4, o, **BOUNDS["stress512_R60"])
     del o
     phi, = run_shards(asora, c, [(0, 4000)])
     assert np.isfinite(phi).all() and (phi >= 0).all() and (phi > 0).mean() > 0.5
     # every source cell received its own (largest nearby) contribution
     assert (phi[pos[:, 0], pos[:, 1], pos[:, 2]] > 0).all()
+
+
+def test_config4_stress512_large_radius(asora, port_oracle, ref_oracle):
+    """BASELINE configs[4] "512^3 ... large R_max": R = 150 at N = 512 -- the launch the library really picks there
+    (column densities only in LDS, ONE 1024-thread workgroup per CU, 1 GiB grids) against the oracle's cube sweep
+    of half-width 150 (raytracing.f90:174-175)."""
+    N = 512
+    nd = tiled_lognormal(N, 128, 3)
+    pos = clustered_sources(nd, 4, 13)
+    flux = np.random.default_rng(6).uniform(0.01, 5.0, 4)
+    c = cases._base(N, 150.0, 3.0 * MPC / 200, pos, flux, ndens=nd, xh=np.full((N, N, N), 2e-4),
+                    table_kw=dict(temp=1e5, numtau=20000))
+    phi, cdh, _ = run_hip(asora, c)
+    info = asora.last_launch_info()
+    assert info["table_driven"] and info["staging"] == "lds-compact" and info["block"] == 1024, info
+    o = cases.run_reference(port_oracle, ref_oracle, c, max_subbox=150, subboxsize=150)
+    check_phi("configs[4] 512^3 log-normal R=150 (lds-compact, 1024 threads), 4 sources", phi, o,
+              **BOUNDS["stress512_R150"])
+    m = (cdh != 0) & (o["coldensh_out"] != 0)
+    assert m.sum() > 10_000_000 and np.array_equal(cdh[m], o["coldensh_out"][m])
+    # the same launch with a long list: what a 1e6-source run on this mesh picks (no oracle: launch shape only)
+    asora.device_init(N, 64, 0, 1)
+    try:
+        asora.photo_table_to_device(c["thin"], c["thick"], int(c["num_tau"]))
+        asora.density_to_device(np.ravel(c["ndens"]), N)
+        many = clustered_sources(nd, 300, 14)
+        asora.source_data_to_device(np.ascontiguousarray(many.ravel()), np.ones(300), 300)
+        cdh2, phi2 = np.zeros(N ** 3), np.zeros(N ** 3)
+        asora.do_all_sources(c["R"], cdh2, c["sig"], c["dr"], None, np.ravel(c["xh"]), phi2, 300, N, c["minlogtau"],
+                             c["dlogtau"], int(c["num_tau"]))
+        info = asora.last_launch_info()
+    finally:
+        asora.device_close()
+    assert info["staging"] == "lds-compact" and info["block"] == 1024 and info["grid"] == 24 * 300, info
+    assert np.isfinite(phi2).all() and (phi2 > 0).all()
+
+
+def test_integer_and_non_integer_radius_256(asora, port_oracle, ref_oracle):
+    """for integer R the cells with d^2 == R^2 sit on a rounding knife-edge of the predicate
+    dist2/dr^2 > R^2 (raytracing.f90:448-451,474); R = 59.5 has no such cells.  Same sources, both radii: the
+    support must be identical to the reference's either way (predicate parity) and the rates within the bar
+    (arithmetic parity); the R = 60 run must reach cells the R = 59.5 run does not."""
+    support = {}
+    for R in (60.0, 59.5):
+        c = bench_case(6, "clustered", R=R)
+        phi, _, _ = run_hip(asora, c)
+        box = int(np.ceil(R))
+        o = cases.run_reference(port_oracle, ref_oracle, c, max_subbox=box, subboxsize=box)
+        check_phi(f"256^3 clustered R={R:g} (knife-edge pair), 6 sources", phi, o, **BOUNDS["knife_edge"])
+        support[R] = phi != 0
+    assert not (support[59.5] & ~support[60.0]).any() and (support[60.0] & ~support[59.5]).sum() > 10_000
+
+
+# Margins measured on MI355X against the compiled reference (profiles/r2_parity_report.json), with head-room of
+# about one order of magnitude on frac_floor; n_sens = 0 everywhere: no full-size config needs the conditioning term.
+BOUNDS = {
+    "bench256_uniform": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
+    "bench256_clustered": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
+    "bench256_R100": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
+    "fullbox256": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
+    "config0": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
+    "eor250": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
+    "stress512_R60": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
+    "stress512_R150": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
+    "knife_edge": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
+}

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import cases
-from parity import compare
+from parity import compare, record
 
 pytestmark = pytest.mark.gpu
 
@@ -61,6 +61,7 @@ def test_phi_vs_golden(asora, golden_dir, name):
     c = load_golden(golden_dir, name)
     phi, cdh, _ = run_hip(asora, c)
     r = compare(phi, c["phi_ion"], sens=c["phi_sens"])
+    record(f"golden {name} (N={c['N']}, R={c['R']:g}, {len(c['flux'])} sources)", r, oracle="reference (golden)")
     print(f"\n[{name}] max_rel={r['max_rel']:.3e} n_rel>1e-10={r['n_rel_gt']} frac_floor={r['frac_floor']:.2e} "
           f"n_sens={r['n_sens']} support_equal={r['support_equal']}")
     if name != "lognormal48":  # the one fixture built to be ill-conditioned (tests/parity.py)

@@ -100,3 +100,19 @@ def test_port_vs_compiled_reference(port_oracle):
     assert relmax(b["phi_ion"], a["phi_ion"]) <= 1e-13
     a0, b0 = cases.run_oracle(ref, c, flux_mode=0), cases.run_oracle(port_oracle, c, flux_mode=0)
     assert relmax(b0["phi_ion"], a0["phi_ion"]) <= 1e-13
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (needs /root/reference + amdflang)")
+def test_port_vs_compiled_reference_bench_config(port_oracle):
+    """The cube sweep every full-size GPU comparison uses (BASELINE configs[1]: 256^3, R = 60, max_subbox = 60,
+    raytracing.f90:174-175) on clustered sources in the log-normal grid: port == compiled reference."""
+    rng = np.random.default_rng(918)
+    N, ns = 256, 2
+    nd = cases.lognormal_density(N, 7, smooth=2.0)
+    p = (nd ** 2).ravel()
+    idx = np.random.default_rng(11).choice(p.size, size=ns, p=p / p.sum())
+    pos = np.stack(np.unravel_index(idx, (N, N, N)), axis=1).astype(np.int32)
+    c = cases._base(N, 60.0, 3.0 * cases.MPC / 200, pos, 4.09e40 * rng.uniform(1e9, 5e11, ns) / 1e48, ndens=nd,
+                    xh=np.full((N, N, N), 2e-4), table_kw=dict(temp=1e5, numtau=20000))
+    o = cases.run_reference(port_oracle, RefOracle(), c, max_subbox=60, subboxsize=60)  # asserts port == reference
+    assert o["kind"] == "reference" and (o["phi_ion"] > 0).sum() > 100_000
