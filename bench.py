@@ -4,6 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) this process only LAUNCHES: it starts N fresh
+ranks through torch.distributed.run as a child (before anything here touches the GPU), relays their output and
+exit code.  A rank whose WORLD_SIZE differs from --gpus exits non-zero.
+
 Workload (config.workload): the reference's raytracing benchmark
 (examples/paper_tests/raytracing_benchmark/run_test.py + parameters.yml) at the mesh BASELINE.json
 names: 256^3 uniform grid (ndens 1e-3, xHII 2e-4, cell 3 Mpc/200), 1e4 random sources, R_max = 60
@@ -105,12 +109,44 @@ def main():
                          "(spatially compact shards) or as given")
     ap.add_argument("--heat", action="store_true", help="also accumulate the photo-heating rate (not the headline config)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="form the process group, count the ranks, print {n_gpus, ranks_seen, backend} and exit "
+                         "(no GPU work: checks the launcher / rendezvous path of a node)")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
     ap.add_argument("--cpu-sources-per-core", type=int, default=48)  # ~15 s of CPU work per core
     a = ap.parse_args()
 
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launcher: N fresh ranks, one per GPU; this process never initialises the GPU (no exec of a GPU process)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if a.rendezvous_only:
+        import torch
+        import torch.distributed as dist
+        backend = os.environ.get("ASORA_BENCH_BACKEND", "gloo")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend)
+        seen = torch.ones(1, dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(seen)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "ranks_seen": int(seen.item()), "backend": backend if world > 1 else None,
+                              "rendezvous_only": True}), flush=True)
+        return
 
     cpu = None
     if rank == 0 and world == 1 and a.gpus == 1 and not a.no_cpu:
@@ -126,6 +162,7 @@ def main():
     ngpu = torch.cuda.device_count()
     dev_index = local_rank % ngpu
     torch.cuda.set_device(dev_index)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("ASORA_BENCH_BACKEND", "nccl")
@@ -174,18 +211,27 @@ def main():
     num_tau = inp["thin"].shape[0]
     stream = torch.cuda.current_stream().cuda_stream
 
+    ar_events = []  # (start, stop) events around the collective of each step, on the launch stream
+
     def step():
         asora.do_all_sources_dev(a.R, 0, 6.30e-18, a.dr, xh_t.data_ptr(), phi_t.data_ptr(),
                                  heat_t.data_ptr() if a.heat else 0, ns_local, N, -20.0, inp["dlogtau"], num_tau, stream)
         if world > 1:
-            if dist.get_backend() == "nccl":
-                dist.all_reduce(phi_t)  # RCCL sum over xGMI, in place on device memory
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if backend == "nccl":
+                # RCCL sum over xGMI, in place on device memory.  The sweep was launched on torch's current stream
+                # (`stream` above) and ProcessGroupNCCL orders its own stream behind the current one on entry and the
+                # current one behind the collective on return: sweep -> all-reduce -> next step's kernels.
+                dist.all_reduce(phi_t)
                 if a.heat:
                     dist.all_reduce(heat_t)
             else:  # single-GPU rehearsal only: through the host
                 h = phi_t.cpu()
                 dist.all_reduce(h)
                 phi_t.copy_(h)
+            e1.record()
+            ar_events.append((e0, e1))
 
     def fence():
         torch.cuda.synchronize()
@@ -200,6 +246,7 @@ def main():
     fence()
     _mark("warm-up done")
     kern_ms = []
+    ar_events.clear()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step()
@@ -209,10 +256,22 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     _mark("timed steps done")
+    # what every rank saw: its sweep-kernel time, its wait + transfer in the collective, and a head count
+    k_ms = float(np.mean(kern_ms))
+    ar_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ar_events])) if ar_events else 0.0
+    per_rank = torch.tensor([dt, k_ms, ar_ms, 1.0, float(ns_local)], dtype=torch.float64, device=dev)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        gathered = [torch.empty_like(per_rank) for _ in range(world)]
+        if backend != "nccl":
+            gathered = [g.cpu() for g in gathered]
+            dist.all_gather(gathered, per_rank.cpu())
+        else:
+            dist.all_gather(gathered, per_rank)
+        allr = torch.stack([g.cpu() for g in gathered]).numpy()
+    else:
+        allr = per_rank.cpu().numpy()[None, :]
+    dt = float(allr[:, 0].max())
+    ranks_seen = int(round(allr[:, 3].sum()))
 
     visits, _ = asora.visit_count(a.R, N)
     in_sphere = asora.geometry_census(a.R, a.dr, N)["owned_rate"]  # the oracle's floating-point sphere test
@@ -221,7 +280,6 @@ def main():
         visits = in_sphere
     total_visits = float(visits) * (ns_local if emu else a.sources)  # rehearsal: this GPU's share only
     value = total_visits * a.steps / dt
-    k_ms = float(np.mean(kern_ms))
     algo_bytes = (32.0 * visits + (32.0 if a.heat else 16.0) * in_sphere) * ns_local  # +16 B per heating-rate update
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
     info = asora.last_launch_info()
@@ -235,6 +293,20 @@ def main():
         except Exception:
             traffic = None
     checksum = float(phi_t.sum().item())
+    # PCIe-inclusive rate of the host-pointer entry point the reference's callers use (asora_do_all_sources: 1 x N^3
+    # up, 1-2 x N^3 down per call, src/asora/raytracing.cu:130,163-166) -- reported beside the headline, never as it
+    host_api = None
+    if rank == 0 and world == 1 and not emu and not a.no_host_api and not a.heat:
+        asora.density_to_device(np.ascontiguousarray(inp["ndens"].ravel()), N)
+        xh_h, phi_h, cdh_h = np.ascontiguousarray(inp["xh"].ravel()), np.zeros(N ** 3), np.zeros(N ** 3)
+        hs = []
+        for _ in range(3):
+            th = time.perf_counter()
+            asora.do_all_sources(a.R, cdh_h, 6.30e-18, a.dr, None, xh_h, phi_h, ns_local, N, -20.0, inp["dlogtau"], num_tau)
+            hs.append(time.perf_counter() - th)
+        host_api = {"ms_per_call": min(hs[1:]) * 1e3, "value": total_visits / min(hs[1:]),
+                    "first_call_ms": hs[0] * 1e3,
+                    "what": "asora_do_all_sources on host pointers: H2D xh_av + sweep + D2H phi_ion and coldensh_out"}
     asora.device_close()
     # second denominator: what a plain device-to-device copy achieves on this box
     copy_gbs = None
@@ -254,7 +326,7 @@ def main():
     if rank == 0:
         line = {
             "metric": "source*cell updates/s, ASORA raytrace", "value": value, "unit": "source*cell updates/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "n_gpus": world, "ranks_seen": ranks_seen, "backend": backend, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"raytracing_benchmark: {N}^3 {a.density} grid, {a.sources} sources, "
@@ -266,12 +338,26 @@ def main():
                        "sources_per_gpu": ns_local, "parallelism": f"source-shard x{world} + all-reduce(phi_ion)",
                        "ns_per_source_per_sphere_cell": dt / a.steps / a.sources / (4.0 / 3.0 * np.pi * a.R ** 3) * 1e9,
                        "phi_checksum": checksum},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "per_rank": {"kernel_ms": [float(v) for v in allr[:, 1]], "allreduce_ms": [float(v) for v in allr[:, 2]],
+                         "step_ms": [float(v) / a.steps * 1e3 for v in allr[:, 0]],
+                         "sources": [int(v) for v in allr[:, 4]]},
+            # `achieved` / `frac` are ALGORITHMIC bytes (32 B per visit + 16 B per rate visit) over the
+            # kernel time against the HBM peak -- the reporting convention of this tier, not measured HBM traffic: the
+            # column density lives in LDS, so the fabric moves about half of that (`traffic`) and the kernel's actual
+            # limiter is VALU issue (profiles/r*_pmc_summary.json)
+            "roofline": {"bound": "hbm", "limiter": "valu-issue (nominal bound: hbm)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "frac_is": "algorithmic bytes / kernel time / peak",
+                         "traffic": traffic,
+                         "traffic_source": ("profiles/hbm_traffic.json (rocprofv3 --pmc passes on this workload, "
+                                            "not this run)") if traffic is not None else None,
+                         "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None, "kernel": "asora::sweep_tab_kernel" if info["table_driven"] else "asora::sweep_kernel",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes,
                          "launch": info},
         }
+        if host_api is not None:
+            line["host_api"] = host_api
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -33,6 +33,11 @@ int asora_device_init(int N, int num_src_par, int mpi_rank, int num_gpus);
 /* replaces asora::device_close, src/asora/memory.cu:138-150 */
 int asora_device_close(void);
 
+/* The HIP device asora_device_init selected (mpi_rank % num_gpus, src/asora/memory.cu:46).  Every entry point makes
+ * that device current for the duration of the call and restores the caller's, so a caller that switched devices in
+ * between stays correct; device pointers handed to the *_dev entry points must live on this device. */
+int asora_device_index(int *device);
+
 /* replaces asora::density_to_device, src/asora/memory.cu:91-98 (host pointer, N*N*N doubles) */
 int asora_density_to_device(const double *ndens, int N);
 
@@ -41,7 +46,11 @@ int asora_density_to_device(const double *ndens, int N);
  * reference's one-past-the-end read (src/asora/rates.cu:96-100) is defined. */
 int asora_photo_table_to_device(const double *thin_table, const double *thick_table, int num_tau);
 
-/* replaces asora::source_data_to_device, src/asora/memory.cu:117-133 */
+/* replaces asora::source_data_to_device, src/asora/memory.cu:117-133.  Positions are PERIODIC like in the
+ * reference (built with -DPERIODIC, src/asora/meson.build:33; every grid access wraps through modulo(i, N),
+ * src/asora/raytracing.cu:32-40): a coordinate outside [0, N) -- e.g. N in a 1-based list handed over unshifted --
+ * addresses cell (coordinate mod N), while the interpolation carries the coordinate as given (raytracing.f90:683),
+ * exactly as both reference codes do.  Only |coordinate| > 2^24 is refused. */
 int asora_source_data_to_device(const int32_t *pos, const double *flux, int num_src);
 
 /* replaces asora::do_all_sources_gpu, src/asora/raytracing.cu:98-169 (Python:

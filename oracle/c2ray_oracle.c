@@ -9,11 +9,12 @@
  * and bench.py's cpu_baseline leg may load it, and only as the checker / reported
  * CPU baseline -- never as a fallback of the HIP path.
  *
- * PINNING: this restatement is pinned bit-for-bit (see tests/test_oracle_vs_ref.py and
- * tests/golden/make_golden.py) against the reference Fortran itself, compiled in the
+ * PINNING: this restatement is pinned bit-for-bit (see tests/test_oracle.py::test_port_vs_compiled_reference*
+ * and tests/golden/make_golden.py) against the reference Fortran itself, compiled in the
  * build container by oracle/Makefile (`make ref`) from the sources where they lie under
  * /root/reference, and against the reference's own fixtures tests/data/cinterp_output_*.npy
- * and photo_ionization_rate.npy (at the level SURVEY.md section 3.4 explains).
+ * and photo_ionization_rate.npy (tests/test_reference_fixtures.py, on the committed copies
+ * tests/golden/ref_*.npy; at the level SURVEY.md section 3.4 explains).
  *
  * Every function cites the reference file:line it follows.  Arithmetic notes that matter
  * for bit-parity (all verified against the flang build):

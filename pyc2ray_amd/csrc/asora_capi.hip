@@ -102,6 +102,37 @@ struct State {
 
 State S;
 
+// The grids, tables and sources live on S.device, and every launch / copy must be issued with that device
+// current.  The caller's thread may have switched devices since asora_device_init (torch.cuda.set_device, another
+// thread): each entry point that touches the device makes S.device current and restores the caller's on return.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    DeviceGuard() {
+        if (!S.init) return;
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != S.device) {
+            err = hipSetDevice(S.device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define ASORA_ON_DEVICE(fn)                                                                                    \
+    DeviceGuard guard_;                                                                                        \
+    if (guard_.err != hipSuccess)                                                                              \
+        return fail(100 + (int)guard_.err, fn ": cannot make device %d current: %s", S.device, hipGetErrorString(guard_.err))
+
+// source coordinates are periodic (the reference wraps them on every access, src/asora/raytracing.cu:32-40)
+inline uint32_t wrapped(int32_t v, int N) {
+    const int r = v % N;
+    return (uint32_t)(r < 0 ? r + N : r);
+}
+constexpr int32_t MAX_SOURCE_COORD = 1 << 24;  // |coordinate| bound: keeps every int / double conversion on the path exact
+
 void free_ptr(double *&p) {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -343,7 +374,7 @@ void sweep_order(const int32_t *pos, int num_src, int N, int order, int *perm) {
     while ((1 << bits) < N) bits++;
     std::vector<uint64_t> key((size_t)num_src);
     for (int i = 0; i < num_src; i++) {
-        const uint32_t x = (uint32_t)pos[3 * (size_t)i], y = (uint32_t)pos[3 * (size_t)i + 1], z = (uint32_t)pos[3 * (size_t)i + 2];
+        const uint32_t x = wrapped(pos[3 * (size_t)i], N), y = wrapped(pos[3 * (size_t)i + 1], N), z = wrapped(pos[3 * (size_t)i + 2], N);
         key[i] = order == 1 ? morton_key(x, y, z, bits) : hilbert_key(x, y, z, bits);
     }
     std::stable_sort(perm, perm + num_src, [&](int a, int b) { return key[a] < key[b]; });
@@ -628,6 +659,7 @@ int do_all_sources_host(double R, double *coldensh_out, double sig, double dr, c
     if (!S.init) return fail(2, "asora_do_all_sources: device not initialised (call asora_device_init)");
     if (m1 != S.N) return fail(3, "asora_do_all_sources: m1=%d differs from device_init N=%d", m1, S.N);
     if (!xh_av || !phi_ion) return fail(9, "asora_do_all_sources: null xh_av / phi_ion pointer");
+    ASORA_ON_DEVICE("asora_do_all_sources");
     const size_t bytes = S.cells * sizeof(double);
     if (int rc = alloc_grid(S.out0)) return rc;
     if (coldensh_out) if (int rc = alloc_grid(S.out1)) return rc;
@@ -673,29 +705,41 @@ int asora_device_init(int N, int num_src_par, int mpi_rank, int num_gpus) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
             S.max_lds = std::max(S.max_lds, std::min(v, 160 * 1024));
     }
-    double **grids[] = {&S.n_dev, &S.x_dev, &S.nhiA, &S.nhiB, &S.phiA, &S.phiB};
-    for (double **g : grids) {
-        hipError_t e = hipMalloc(g, S.cells * sizeof(double));
-        if (e != hipSuccess) {
-            for (double **h : grids) free_ptr(*h);
-            return fail(100 + (int)e, "asora_device_init: hipMalloc of %zu bytes failed: %s", S.cells * sizeof(double),
-                        hipGetErrorString(e));
+    S.init = true;  // from here on asora_device_close releases whatever exists
+    const int rc = [&]() -> int {
+        double **grids[] = {&S.n_dev, &S.x_dev, &S.nhiA, &S.nhiB, &S.phiA, &S.phiB};
+        for (double **g : grids) {
+            hipError_t e = hipMalloc(g, S.cells * sizeof(double));
+            if (e != hipSuccess)
+                return fail(100 + (int)e, "asora_device_init: hipMalloc of %zu bytes failed: %s", S.cells * sizeof(double),
+                            hipGetErrorString(e));
         }
-    }
-    {
         double tab[asora::LOG10_TABLE_DOUBLES];
         asora::build_log10_table(tab);
         HIP_TRY(hipMalloc(&S.log10_table, sizeof tab));
         HIP_TRY(hipMemcpy(S.log10_table, tab, sizeof tab, hipMemcpyHostToDevice));
+        HIP_TRY(hipEventCreate(&S.ev0));
+        HIP_TRY(hipEventCreate(&S.ev1));
+        return 0;
+    }();
+    if (rc) {  // any failure after the first allocation: give everything back, keep the message
+        const std::string msg = g_err;
+        (void)asora_device_close();
+        g_err = msg;
     }
-    HIP_TRY(hipEventCreate(&S.ev0));
-    HIP_TRY(hipEventCreate(&S.ev1));
-    S.init = true;
+    return rc;
+}
+
+int asora_device_index(int *device) {
+    if (!device) return fail(9, "asora_device_index: null pointer");
+    if (!S.init) return fail(2, "asora_device_index: device not initialised");
+    *device = S.device;
     return 0;
 }
 
 int asora_device_close(void) {
     if (!S.init) return fail(2, "asora_device_close: device not initialised");
+    ASORA_ON_DEVICE("asora_device_close");
     (void)hipDeviceSynchronize();
     double **grids[] = {&S.n_dev, &S.x_dev, &S.nhiA, &S.nhiB, &S.phiA, &S.phiB, &S.heatA, &S.heatB, &S.cdhA,
                         &S.cdhB, &S.out0, &S.out1, &S.out2, &S.thin, &S.thick, &S.hthin, &S.hthick,
@@ -713,7 +757,9 @@ int asora_device_close(void) {
     fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.compact_staging = S.compact_staging; fresh.quad_kernel = S.quad_kernel; fresh.quad_max_entries = S.quad_max_entries; fresh.oct_max_entries = S.oct_max_entries; fresh.last_quad = S.last_quad; fresh.max_table_cells = S.max_table_cells;
     fresh.last_tab = S.last_tab; fresh.last_grid = S.last_grid; fresh.last_block = S.last_block;
     fresh.last_lds = S.last_lds; fresh.last_is_lds = S.last_is_lds;
+    const int dev = S.device;
     S = fresh;
+    S.device = dev;  // (the guard above still restores the caller's device)
     return 0;
 }
 
@@ -721,6 +767,7 @@ int asora_density_to_device(const double *ndens, int N) {
     if (!S.init) return fail(2, "asora_density_to_device: device not initialised");
     if (N != S.N) return fail(3, "asora_density_to_device: N=%d differs from device_init N=%d", N, S.N);
     if (!ndens) return fail(9, "asora_density_to_device: null pointer");
+    ASORA_ON_DEVICE("asora_density_to_device");
     HIP_TRY(hipMemcpy(S.n_dev, ndens, S.cells * sizeof(double), hipMemcpyHostToDevice));
     return 0;
 }
@@ -729,6 +776,7 @@ int asora_density_from_device(const double *ndens_dev, int N, void *stream) {
     if (!S.init) return fail(2, "asora_density_from_device: device not initialised");
     if (N != S.N) return fail(3, "asora_density_from_device: N=%d differs from device_init N=%d", N, S.N);
     if (!ndens_dev) return fail(9, "asora_density_from_device: null pointer");
+    ASORA_ON_DEVICE("asora_density_from_device");
     HIP_TRY(hipMemcpyAsync(S.n_dev, ndens_dev, S.cells * sizeof(double), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
     return 0;
@@ -737,6 +785,7 @@ int asora_density_from_device(const double *ndens_dev, int N, void *stream) {
 int asora_photo_table_to_device(const double *thin_table, const double *thick_table, int num_tau) {
     if (!S.init) return fail(2, "asora_photo_table_to_device: device not initialised");
     if (num_tau < 1 || !thin_table || !thick_table) return fail(9, "asora_photo_table_to_device: bad arguments");
+    ASORA_ON_DEVICE("asora_photo_table_to_device");
     if (int rc = upload_table(S.thin, thin_table, num_tau)) return rc;
     if (int rc = upload_table(S.thick, thick_table, num_tau)) return rc;
     S.table_len = num_tau;
@@ -746,6 +795,7 @@ int asora_photo_table_to_device(const double *thin_table, const double *thick_ta
 int asora_heat_table_to_device(const double *heat_thin_table, const double *heat_thick_table, int num_tau) {
     if (!S.init) return fail(2, "asora_heat_table_to_device: device not initialised");
     if (num_tau < 1 || !heat_thin_table || !heat_thick_table) return fail(9, "asora_heat_table_to_device: bad arguments");
+    ASORA_ON_DEVICE("asora_heat_table_to_device");
     if (int rc = upload_table(S.hthin, heat_thin_table, num_tau)) return rc;
     if (int rc = upload_table(S.hthick, heat_thick_table, num_tau)) return rc;
     S.heat_table_len = num_tau;
@@ -756,7 +806,8 @@ int asora_source_order(const int32_t *pos, int num_src, int m1, int order, int32
     if (num_src < 0 || m1 < 1 || order < 0 || order > 2 || (num_src > 0 && (!pos || !perm)))
         return fail(9, "asora_source_order: bad arguments");
     for (int i = 0; i < 3 * num_src; i++)
-        if (pos[i] < 0 || pos[i] >= m1) return fail(10, "asora_source_order: source %d outside [0, %d)", i / 3, m1);
+        if (pos[i] < -MAX_SOURCE_COORD || pos[i] > MAX_SOURCE_COORD)
+            return fail(10, "asora_source_order: source %d coordinate %d = %d is not a grid position", i / 3, i % 3, pos[i]);
     sweep_order(pos, num_src, m1, order, perm);
     return 0;
 }
@@ -764,10 +815,14 @@ int asora_source_order(const int32_t *pos, int num_src, int m1, int order, int32
 int asora_source_data_to_device(const int32_t *pos, const double *flux, int num_src) {
     if (!S.init) return fail(2, "asora_source_data_to_device: device not initialised");
     if (num_src < 0 || (num_src > 0 && (!pos || !flux))) return fail(9, "asora_source_data_to_device: bad arguments");
+    // Positions are periodic like in the reference (-DPERIODIC, src/asora/meson.build:33: every access goes through
+    // modulo(i, N), raytracing.cu:32-40), e.g. the 1-based lists of pyc2ray's read_sources / generate_test_sourcefile
+    // (1 .. N) run as they are.  Only values that cannot be grid positions at all are refused.
     for (int i = 0; i < 3 * num_src; i++)
-        if (pos[i] < 0 || pos[i] >= S.N)
-            return fail(10, "asora_source_data_to_device: source %d coordinate %d = %d outside [0, %d)", i / 3, i % 3,
-                        pos[i], S.N);
+        if (pos[i] < -MAX_SOURCE_COORD || pos[i] > MAX_SOURCE_COORD)
+            return fail(10, "asora_source_data_to_device: source %d coordinate %d = %d is not a grid position", i / 3,
+                        i % 3, pos[i]);
+    ASORA_ON_DEVICE("asora_source_data_to_device");
     // the reference re-allocates on every call and never frees (memory.cu:121,127); we do free
     if (S.src_pos) (void)hipFree(S.src_pos);
     if (S.src_flux) (void)hipFree(S.src_flux);
@@ -804,6 +859,7 @@ int asora_do_all_sources_heat(double R, double *coldensh_out, double sig, double
 int asora_do_all_sources_dev(double R, double *coldensh_out_dev, double sig, double dr, const double *xh_av_dev,
                              double *phi_ion_dev, double *phi_heat_dev, int num_src, int m1, double minlogtau,
                              double dlogtau, int num_tau, void *stream) {
+    ASORA_ON_DEVICE("asora_do_all_sources_dev");
     return do_all_sources_impl(R, coldensh_out_dev, sig, dr, xh_av_dev, phi_ion_dev, phi_heat_dev, num_src, m1,
                                minlogtau, dlogtau, num_tau, (hipStream_t)stream);
 }
@@ -818,6 +874,7 @@ int asora_global_pass_dev(double dt, const double *ndens_dev, const double *temp
     if (m1 < 1) return fail(9, "asora_global_pass_dev: bad mesh size %d", m1);
     if (!ndens_dev || !temp_dev || !xh_dev || !xh_av_dev || !xh_intermed_dev || !phi_ion_dev || !clump_dev)
         return fail(9, "asora_global_pass_dev: null grid pointer");
+    ASORA_ON_DEVICE("asora_global_pass_dev");
     hipStream_t st = (hipStream_t)stream;
     if (!S.chem_stats) HIP_TRY(hipMalloc(&S.chem_stats, sizeof(asora::ChemStats)));
     HIP_TRY(hipMemsetAsync(S.chem_stats, 0, sizeof(asora::ChemStats), st));
@@ -848,6 +905,7 @@ int asora_global_pass(double dt, const double *ndens, const double *temp, const 
     if (m1 != S.N) return fail(3, "asora_global_pass: m1=%d differs from device_init N=%d", m1, S.N);
     if (!ndens || !temp || !xh || !xh_av || !xh_intermed || !phi_ion || !clump || !conv_flag)
         return fail(9, "asora_global_pass: null pointer");
+    ASORA_ON_DEVICE("asora_global_pass");
     const size_t bytes = S.cells * sizeof(double);
     for (double *&b : S.chem_buf)
         if (int rc = alloc_grid(b)) return rc;
@@ -957,6 +1015,7 @@ int asora_geometry_census(double R, double dr, int m1, long long *owned, long lo
 int asora_last_sweep_ms(float *ms) {
     if (!ms) return fail(9, "asora_last_sweep_ms: null pointer");
     if (!S.init || !S.timed) return fail(11, "asora_last_sweep_ms: no sweep has been timed");
+    ASORA_ON_DEVICE("asora_last_sweep_ms");
     HIP_TRY(hipEventSynchronize(S.ev1));
     HIP_TRY(hipEventElapsedTime(ms, S.ev0, S.ev1));
     return 0;

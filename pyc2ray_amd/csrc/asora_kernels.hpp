@@ -69,7 +69,7 @@ struct SweepArgs {
     double *phiA, *phiB;    // rate accumulators in the two layouts
     double *heatA, *heatB;  // heating accumulators (HEAT only)
     double *cdhA, *cdhB;    // column density of source `cdh_src` in the two layouts (may be null)
-    const int *src_pos;     // 0-based, interleaved
+    const int *src_pos;     // 0-based, interleaved, as given by the caller (may lie outside [0, N): periodic)
     const double *src_flux;
     const double *thick, *thin, *hthick, *hthin;  // padded tables
     const double *log10_table;                    // LOG10_TABLE_DOUBLES doubles (asora_log10.hpp)
@@ -306,6 +306,13 @@ __device__ __forceinline__ void cinterp_sector(int n, int a, int b, int su, int 
     path = cinterp_path(n, a, b);
 }
 
+// Fortran-type modulo (src/asora/raytracing.cu:32): source positions may lie outside [0, N) -- the reference wraps
+// them on every grid access (mem_offst_gpu) while its interpolation carries the coordinate AS GIVEN
+// (raytracing.f90:683 xc = alam*di + real(i0)), so both forms are kept: wrapped for addressing, raw for arithmetic.
+__device__ __forceinline__ int fmodulo(int a, int N) {
+    const int r = a % N;
+    return r < 0 ? r + N : r;
+}
 __device__ __forceinline__ int wrap(int x, int N) {
     x += (x < 0) ? N : 0;
     x -= (x >= N) ? N : 0;
@@ -352,12 +359,13 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
         const int sp = (t & 4) ? -1 : 1;
         const int su = (t & 2) ? -1 : 1;
         const int sv = (t & 1) ? -1 : 1;
-        const int i0 = A.src_pos[3 * src + 0], j0 = A.src_pos[3 * src + 1], k0 = A.src_pos[3 * src + 2];
+        const int i0r = A.src_pos[3 * src + 0], j0r = A.src_pos[3 * src + 1], k0r = A.src_pos[3 * src + 2];
+        const int i0 = fmodulo(i0r, A.N), j0 = fmodulo(j0r, A.N), k0 = fmodulo(k0r, A.N);
         const double flux = A.src_flux[src];
-        int p0, u0, v0;
-        if (axis == 0) { p0 = k0; u0 = i0; v0 = j0; }
-        else if (axis == 1) { p0 = j0; u0 = i0; v0 = k0; }
-        else { p0 = i0; u0 = j0; v0 = k0; }
+        int p0, u0, v0, ur1, vr1;  // wrapped position (addressing); 1-based in-plane coordinates as given (arithmetic)
+        if (axis == 0) { p0 = k0; u0 = i0; v0 = j0; ur1 = i0r + 1; vr1 = j0r + 1; }
+        else if (axis == 1) { p0 = j0; u0 = i0; v0 = k0; ur1 = i0r + 1; vr1 = k0r + 1; }
+        else { p0 = i0; u0 = j0; v0 = k0; ur1 = j0r + 1; vr1 = k0r + 1; }
         const double *__restrict__ nhi = (axis == 0) ? A.nhiB : A.nhiA;
         double *__restrict__ phi = (axis == 0) ? A.phiB : A.phiA;
         double *__restrict__ heat = (axis == 0) ? A.heatB : A.heatA;
@@ -415,7 +423,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
                 const double c3 = stg.ld(prev + a * S + b + 1);
                 const double c4 = stg.ld(prev + (a + 1) * S + b + 1);
                 double cdh_in, path;
-                cinterp_sector(n, a, b, su, sv, u0 + 1, v0 + 1, c1, c2, c3, c4, A.sig, SQRT3_F32, SQRT2_F32,
+                cinterp_sector(n, a, b, su, sv, ur1, vr1, c1, c2, c3, c4, A.sig, SQRT3_F32, SQRT2_F32,
                                cdh_in, path);
                 path = path * A.dr;
                 // raytracing.f90:448-451: dist2 = xs*xs + ys*ys + zs*zs in x, y, z order
@@ -699,11 +707,12 @@ void sweep_tab_kernel(SweepArgs A) {
         const int sp = OCT ? ((quad & 4) ? -1 : 1) : ((t & 4) ? -1 : 1);  // OCT: per lane
         const int su = QUAD ? ((quad & 2) ? -1 : 1) : ((t & 2) ? -1 : 1);  // QUAD: per lane
         const int sv = QUAD ? ((quad & 1) ? -1 : 1) : ((t & 1) ? -1 : 1);
-        const int i0 = A.src_pos[3 * src + 0], j0 = A.src_pos[3 * src + 1], k0 = A.src_pos[3 * src + 2];
-        int p0, u0, v0;
-        if (axis == 0) { p0 = k0; u0 = i0; v0 = j0; }
-        else if (axis == 1) { p0 = j0; u0 = i0; v0 = k0; }
-        else { p0 = i0; u0 = j0; v0 = k0; }
+        const int i0r = A.src_pos[3 * src + 0], j0r = A.src_pos[3 * src + 1], k0r = A.src_pos[3 * src + 2];
+        const int i0 = fmodulo(i0r, N), j0 = fmodulo(j0r, N), k0 = fmodulo(k0r, N);
+        int p0, u0, v0, ur1, vr1;  // wrapped position (addressing); 1-based in-plane coordinates as given (arithmetic)
+        if (axis == 0) { p0 = k0; u0 = i0; v0 = j0; ur1 = i0r + 1; vr1 = j0r + 1; }
+        else if (axis == 1) { p0 = j0; u0 = i0; v0 = k0; ur1 = i0r + 1; vr1 = k0r + 1; }
+        else { p0 = i0; u0 = j0; v0 = k0; ur1 = j0r + 1; vr1 = k0r + 1; }
         const double flux = A.src_flux[src];
         const double *__restrict__ nhi = (axis == 0) ? A.nhiB : A.nhiA;
         double *__restrict__ phi = (axis == 0) ? A.phiB : A.phiA;
@@ -756,8 +765,8 @@ void sweep_tab_kernel(SweepArgs A) {
             const double alam = planes[1].alam;
             for (int i = tid; i < 2 * SW; i += THREADS) {
                 const int j = i < SW ? i : i - SW, o = j >= W ? j - W : j;
-                if (i < SW) du_tab[j] = interp_offsets(o, table_dir(j, su), u0 + 1, alam);
-                else dv_tab[j] = interp_offsets(o, table_dir(j, sv), v0 + 1, alam);
+                if (i < SW) du_tab[j] = interp_offsets(o, table_dir(j, su), ur1, alam);
+                else dv_tab[j] = interp_offsets(o, table_dir(j, sv), vr1, alam);
             }
         }
         __syncthreads();
@@ -951,8 +960,8 @@ void sweep_tab_kernel(SweepArgs A) {
                 const double alam_next = planes[min(n + 1, A.nplanes - 1)].alam;
                 for (int i = tid; i < 2 * SW; i += THREADS) {
                     const int j = i < SW ? i : i - SW, o = j >= W ? j - W : j;
-                    if (i < SW) du_tab[j] = interp_offsets(o, table_dir(j, su), u0 + 1, alam_next);
-                    else dv_tab[j] = interp_offsets(o, table_dir(j, sv), v0 + 1, alam_next);
+                    if (i < SW) du_tab[j] = interp_offsets(o, table_dir(j, su), ur1, alam_next);
+                    else dv_tab[j] = interp_offsets(o, table_dir(j, sv), vr1, alam_next);
                 }
             }
             phase_barrier<LDS_STAGE>();  // new values visible

@@ -17,7 +17,8 @@
 // true value wherever |log10 x| >~ 2^-6 and within ~2^-58 absolute everywhere (the lookups add
 // 20 to it, so absolute accuracy near x = 1 is what matters).  Domain: finite normal x > 0
 // (the path clamps tau to >= 1e-20).  Checked against 80-bit log10l on the host
-// (tests/test_boundary.py::test_log10_host) and against glibc on the device (-m gpu).
+// (tests/host/log10_check.cpp, compiled and run by tests/test_boundary.py::test_log10_table_against_long_double);
+// the device runs the same source (the rates of every -m gpu parity test go through it).
 #pragma once
 #include <stdint.h>
 

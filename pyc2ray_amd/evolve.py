@@ -107,14 +107,15 @@ def evolve3D(dt, dr, src_flux, src_pos, use_gpu, max_subbox, subboxsize, loss_fr
     srcpos_flat, normflux_flat = format_sources(src_pos[:, lo:hi], src_flux[lo:hi])
     libasora.source_data_to_device(srcpos_flat, normflux_flat, NumSrc)
 
-    dev = torch.device("cuda", torch.cuda.current_device())
+    # the library's grids live on the device device_init selected: the step's tensors must live there too
+    dev = torch.device("cuda", libasora.device_index())
     up = lambda a: torch.from_numpy(np.ravel(a).astype("float64", copy=True)).to(dev)
     ndens_t, temp_t, xh_t, clump_t = up(ndens), up(temp), up(xh), up(clump)
     xh_av_t = xh_t.clone()
     xh_intermed_t = xh_t.clone()
     phi_t = torch.zeros(NumCells, dtype=torch.float64, device=dev)
     cdh_t = torch.zeros(NumCells, dtype=torch.float64, device=dev) if want_coldens else None
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = torch.cuda.current_stream(dev).cuda_stream
     libasora.density_from_device(ndens_t.data_ptr(), N, stream)
 
     def raytrace():

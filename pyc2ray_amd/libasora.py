@@ -17,8 +17,23 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ASORA_HIP_LIB: alternative build of the same library (A/B experiments); never a fallback
-LIB_PATH = os.environ.get("ASORA_HIP_LIB") or os.path.join(_HERE, "lib", "libasora_hip.so")
+
+
+def _find_library():
+    """libasora_hip.so next to this file (the drop-in layout: both files copied into ``pyc2ray/lib/``, where the
+    reference's meson build installs its extension, src/asora/meson.build:39-64) or in ``lib/`` below it (this
+    repository's layout).  ASORA_HIP_LIB names an alternative build of the same library (A/B experiments); it is
+    never a fallback."""
+    if os.environ.get("ASORA_HIP_LIB"):
+        return os.environ["ASORA_HIP_LIB"]
+    cands = [os.path.join(_HERE, "libasora_hip.so"), os.path.join(_HERE, "lib", "libasora_hip.so")]
+    for p in cands:
+        if os.path.exists(p):
+            return p
+    return cands[-1]
+
+
+LIB_PATH = _find_library()
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -27,6 +42,7 @@ _ip = C.POINTER(C.c_int32)
 ABI = {
     "asora_device_init": (C.c_int, [C.c_int] * 4),
     "asora_device_close": (C.c_int, []),
+    "asora_device_index": (C.c_int, [C.POINTER(C.c_int)]),
     "asora_density_to_device": (C.c_int, [_dp, C.c_int]),
     "asora_photo_table_to_device": (C.c_int, [_dp, _dp, C.c_int]),
     "asora_source_data_to_device": (C.c_int, [_ip, _dp, C.c_int]),
@@ -122,6 +138,13 @@ def device_close():
     _check(_lib.asora_device_close())
 
 
+def device_index():
+    """The HIP device ``device_init`` selected (``mpi_rank % num_gpus``)."""
+    d = C.c_int(-1)
+    _check(_lib.asora_device_index(C.byref(d)))
+    return d.value
+
+
 def density_to_device(ndens, N):
     """Copy the density grid (flat float64, N^3) to the device (memory.cu:91-98)."""
     N = int(N)
@@ -142,7 +165,8 @@ def heat_table_to_device(heat_thin_table, heat_thick_table, num_tau):
 
 
 def source_data_to_device(pos, flux, num_src):
-    """Copy source positions (int32, x0,y0,z0,x1,... 0-based) and fluxes (memory.cu:117-133)."""
+    """Copy source positions (int32, x0,y0,z0,x1,... 0-based, periodic: a coordinate outside [0, N) addresses
+    cell ``coordinate % N`` like in the reference) and fluxes (memory.cu:117-133)."""
     n = int(num_src)
     if not isinstance(pos, np.ndarray) or pos.dtype != np.int32 or not pos.flags.c_contiguous or pos.size < 3 * n:
         raise TypeError("pos must be a C-contiguous int32 array with 3*num_src entries")

@@ -168,8 +168,11 @@ def test_source_sweep_order():
     dup = np.array([[5, 5, 5], [1, 2, 3], [5, 5, 5], [5, 5, 5]], dtype=np.int32)
     perm = la.source_order(dup.ravel(), 8, 2)
     assert [int(i) for i in perm if i != 1] == [0, 2, 3]
+    # positions are periodic: a list shifted by multiples of N sorts like the list itself
+    assert np.array_equal(la.source_order((pos + np.array([100, -200, 0], dtype=np.int32)).ravel(), 100, 2),
+                          la.source_order(pos.ravel(), 100, 2))
     with pytest.raises(RuntimeError):
-        la.source_order(np.array([0, 0, 9], dtype=np.int32), 8, 2)
+        la.source_order(np.array([0, 0, 1 << 30], dtype=np.int32), 8, 2)
     assert la.source_order(np.zeros(0, dtype=np.int32), 8, 2).size == 0
 
 
@@ -195,3 +198,35 @@ def test_cbin_round_trip(tmp_path):
     assert np.array_equal(read_cbin(str(tmp_path / "run_IonRates_z7.059.dat"), bits=32, order="F"), (2 * a).astype(np.float32))
     with pytest.raises(ValueError):
         read_cbin(f, bits=64, order="C")  # wrong width: fewer values than the header promises
+
+
+def test_log10_table_against_long_double(tmp_path):
+    """asora_log10.hpp (the sweep's log10, photorates.f90:139) on the host against 80-bit log10l over 4e6 points of
+    the lookups' domain: <= 0.55 ulp wherever |log10 x| > 1e-2 (the claim in the header's comment, guarded).  glibc's
+    log10 -- the function the reference Fortran calls -- is itself up to ~2 ulp off, so the two differ in ~19 % of
+    the results, by at most 2 ulp and by more than 1.5 ulp in fewer than one result in 1e5; tests/parity.py's
+    conditioning term covers exactly that libm-to-libm variation."""
+    import subprocess
+    exe = str(tmp_path / "log10_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                           os.path.join(ROOT, "tests", "host", "log10_check.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, check=True).stdout.split()
+    max_ulp, max_abs, frac_not_cr, frac_ne_glibc = (float(v) for v in out[:4])
+    n_far, max_glibc_ulp = int(out[4]), float(out[5])
+    assert max_ulp <= 0.55 and max_abs <= 2.0 ** -54, out   # (absolute: half an ulp of 20, the largest |log10 tau|)
+    assert frac_not_cr < 0.2 and frac_ne_glibc < 0.2, out
+    assert n_far <= 40 and max_glibc_ulp <= 2.0, out         # of 4e6
+
+
+def test_meson_build_runs_the_same_compiler_line():
+    """meson is not installed in the development image, so meson.build is never executed here: at least its flag
+    list must stay identical to the command __graft_entry__.build() runs."""
+    import __graft_entry__ as g
+    txt = open(os.path.join(ROOT, "meson.build")).read()
+    cmd = re.search(r"command\s*:\s*\[(.*?)\]", txt, flags=re.S).group(1)
+    toks = re.findall(r"'([^']*)'", cmd)
+    assert "--offload-arch=" in toks and "get_option('gpu-architecture')" in txt
+    flags = [t for t in toks if t not in ("--offload-arch=", "-o", "@OUTPUT@", "@INPUT@")]
+    assert flags == [f for f in g.HIP_FLAGS if not f.startswith("--offload-arch")], (flags, g.HIP_FLAGS)
+    opt = open(os.path.join(ROOT, "meson.options")).read()
+    assert "gfx950" in opt and "--offload-arch=gfx950" in g.HIP_FLAGS

@@ -60,3 +60,30 @@ def test_shard_and_allreduce_world2(tmp_path, port_oracle):
     m = ref != 0
     assert np.max(np.abs(p0[m] - ref[m]) / ref[m]) < 1e-13   # only the summation order differs
     assert np.array_equal(p0 != 0, m)
+
+
+def _bench(*args, env=None):
+    import subprocess
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                          timeout=300, cwd=ROOT, env=e)
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_n_launches_n_ranks():
+    """`python bench.py --gpus 2` with no launcher environment must START two ranks (torch.distributed.run as a
+    child, before anything touches a GPU) and count them; --rendezvous-only stops after the head count, so this
+    runs on CPU with gloo."""
+    import json
+    r = _bench("--gpus", "2", "--rendezvous-only", env={"ASORA_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["backend"] == "gloo"
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    r = _bench("--gpus", "4", "--rendezvous-only", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    r = _bench("--gpus", "1", "--rendezvous-only")
+    assert r.returncode == 0 and '"ranks_seen": 1' in r.stdout

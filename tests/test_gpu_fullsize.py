@@ -265,7 +265,7 @@ def test_config4_stress512_large_radius(asora, port_oracle, ref_oracle):
     finally:
         asora.device_close()
     assert info["staging"] == "lds-compact" and info["block"] == 1024 and info["grid"] == 24 * 300, info
-    assert np.isfinite(phi2).all() and (phi2 > 0).all()
+    assert np.isfinite(phi2).all() and (phi2 >= 0).all() and (phi2[many[:, 0], many[:, 1], many[:, 2]] > 0).all()
 
 
 def test_integer_and_non_integer_radius_256(asora, port_oracle, ref_oracle):
@@ -284,16 +284,10 @@ def test_integer_and_non_integer_radius_256(asora, port_oracle, ref_oracle):
     assert not (support[59.5] & ~support[60.0]).any() and (support[60.0] & ~support[59.5]).sum() > 10_000
 
 
-# Margins measured on MI355X against the compiled reference (profiles/r2_parity_report.json), with head-room of
-# about one order of magnitude on frac_floor; n_sens = 0 everywhere: no full-size config needs the conditioning term.
-BOUNDS = {
-    "bench256_uniform": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
-    "bench256_clustered": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
-    "bench256_R100": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
-    "fullbox256": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
-    "config0": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
-    "eor250": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
-    "stress512_R60": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
-    "stress512_R150": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
-    "knife_edge": dict(max_sens=0, max_frac_floor=1e-5, max_rel=1e-9),
-}
+# Margins: measured on MI355X against the compiled reference (profiles/r2_parity_report.json: n_sens = 0 everywhere --
+# no full-size config needs the conditioning term --, at most 5 of 1.7e7 cells (3e-7) on the absolute floor, worst
+# pure-relative error 2.6e-10 on one of those floor cells), with an order of magnitude of head-room on the floor
+# fraction and a factor of 4 on the worst relative error.
+_B = dict(max_sens=0, max_frac_floor=3e-6, max_rel=1e-9)
+BOUNDS = {k: _B for k in ("bench256_uniform", "bench256_clustered", "bench256_R100", "fullbox256", "config0", "eor250",
+                          "stress512_R60", "stress512_R150", "knife_edge")}

@@ -29,12 +29,22 @@ def test_two_rank_bench_reproduces_single_rank_checksum():
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *ARGS], capture_output=True, text=True,
                          timeout=300, cwd=ROOT, env=env)
     assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    # the driver's plain command form: bench.py itself starts the two ranks
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *ARGS], capture_output=True,
+                         text=True, timeout=300, cwd=ROOT, env={k: v for k, v in env.items() if k not in
+                                                                 ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = _last_json(one.stdout), _last_json(two.stdout)
+    assert b["n_gpus"] == 2 and b["ranks_seen"] == 2 and b["backend"] == "gloo"
+    assert b["per_rank"]["sources"] == [240, 241] and len(b["per_rank"]["kernel_ms"]) == 2
+    assert all(v > 0 for v in b["per_rank"]["kernel_ms"] + b["per_rank"]["allreduce_ms"])
+    assert a["n_gpus"] == 1 and a["ranks_seen"] == 1 and a["per_rank"]["allreduce_ms"] == [0.0]
+    # and under an external launcher (the driver's other form)
+    ext = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                           os.path.join(ROOT, "bench.py"), "--gpus", "2", *ARGS], capture_output=True, text=True,
                          timeout=300, cwd=ROOT, env=env)
-    assert two.returncode == 0, two.stderr[-2000:]
-    a, b = _last_json(one.stdout), _last_json(two.stdout)
-    assert b["n_gpus"] == 2 and b["config"]["sources_per_gpu"] in (240, 241)
+    assert ext.returncode == 0, ext.stderr[-2000:]
+    assert _last_json(ext.stdout)["ranks_seen"] == 2
     ca, cb = a["config"]["phi_checksum"], b["config"]["phi_checksum"]
     assert ca > 0 and abs(ca - cb) <= 1e-12 * ca, (ca, cb)  # sum order differs, nothing else

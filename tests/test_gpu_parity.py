@@ -123,6 +123,33 @@ def test_tiny_radius_vs_oracle(asora, port_oracle, R):
     assert (phi != 0).sum() >= 2
 
 
+@pytest.mark.parametrize("opts", [dict(), dict(quad_kernel=-1), dict(force_generic=1), dict(source_order=0)])
+def test_source_positions_are_periodic(asora, port_oracle, ref_oracle, opts):
+    """The reference is built with -DPERIODIC (src/asora/meson.build:33): source coordinates outside [0, N) -- the
+    1-based lists of read_sources / generate_test_sourcefile contain N -- address cell (coordinate mod N), while the
+    interpolation carries the coordinate as given (raytracing.f90:683).  Against the oracle fed the same list:
+    the usual bar for the rates, bit-identical column density (which a wrap on upload would not give: the
+    rounding of alam*di + real(i0) depends on i0)."""
+    N = 24
+    c = cases._base(N, 9.0, 5e20, [[N, -1, 5], [3, N + 2, -N - 3], [2 * N, 7, 7]], [1.0, 2.0, 0.5],
+                    ndens=cases.lognormal_density(N, 4))
+    for k, v in opts.items():
+        asora.set_option(k, v)
+    try:
+        phi, cdh, _ = run_hip(asora, c)
+    finally:
+        for k in opts:
+            asora.set_option(k, {"source_order": 2}.get(k, 0))
+    o = cases.run_reference(port_oracle, ref_oracle, c)
+    r = compare(phi, o["phi_ion"], sens=o["phi_sens"])
+    assert r["ok"] and r["support_equal"] and r["n_sens"] == 0, r
+    m = cdh != 0
+    assert m.sum() == asora.visit_count(c["R"], N)[0] and np.array_equal(cdh[m], o["coldensh_out"][m])
+    # the wrapped list gives the same grid up to that rounding
+    phi_w, _, _ = run_hip(asora, dict(c, pos=np.mod(c["pos"], N).astype(np.int32)))
+    assert np.allclose(phi_w, phi, rtol=1e-11, atol=0) and np.array_equal(phi_w != 0, phi != 0)
+
+
 def test_empty_source_list(asora, golden_dir):
     c = load_golden(golden_dir, "uniform32_center")
     phi, cdh, _ = run_hip(asora, c, num_src=0)
@@ -346,8 +373,9 @@ def test_error_reporting(asora):
     try:
         with pytest.raises(RuntimeError):  # tables missing
             asora.do_all_sources(1.0, np.zeros(512), 1.0, 1.0, None, np.zeros(512), np.zeros(512), 0, 8, -20.0, 0.1, 10)
-        with pytest.raises(RuntimeError):  # source outside the box
-            asora.source_data_to_device(np.array([0, 0, 8], dtype=np.int32), np.ones(1), 1)
+        asora.source_data_to_device(np.array([0, 0, 8], dtype=np.int32), np.ones(1), 1)  # periodic, like the reference
+        with pytest.raises(RuntimeError):  # not a grid position at all
+            asora.source_data_to_device(np.array([0, 0, 1 << 30], dtype=np.int32), np.ones(1), 1)
         with pytest.raises(TypeError):
             asora.density_to_device(np.zeros(512, dtype=np.float32), 8)
     finally:
