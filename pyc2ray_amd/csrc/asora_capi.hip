@@ -727,6 +727,8 @@ int asora_device_init(int N, int num_src_par, int mpi_rank, int num_gpus) {
         HIP_TRY(hipMemcpy(S.log10_table, tab, sizeof tab, hipMemcpyHostToDevice));
         HIP_TRY(hipEventCreate(&S.ev0));
         HIP_TRY(hipEventCreate(&S.ev1));
+        // set-up of the entry point that allocates nothing: this device's copy of the scratch array (each GPU holds
+        // its own, at its own address) and a page-locked landing buffer for its three results
         return 0;
     }();
     if (rc) {  // any failure after the first allocation: give everything back, keep the message
@@ -872,6 +874,33 @@ int asora_do_all_sources_dev(double R, double *coldensh_out_dev, double sig, dou
 }
 
 // ---- chemistry pass (asora_chem.hpp) ---------------------------------------------------------
+// One chemistry pass; `stats` is the device record the kernel reduces into (zeroed here), `landing` a host buffer
+// the three results are copied to when the caller wants them (the call then waits for the stream).
+static int global_pass_launch(double dt, const double *ndens_dev, const double *temp_dev, const double *xh_dev,
+                              double *xh_av_dev, double *xh_intermed_dev, const double *phi_ion_dev,
+                              const double *clump_dev, double bh00, double albpow, double colh0, double temph0,
+                              double abu_c, int m1, long long *conv_flag, double *sum_xh1, double *sum_xh0,
+                              hipStream_t st, asora::ChemStats *stats, asora::ChemStats *landing) {
+    HIP_TRY(hipMemsetAsync(stats, 0, sizeof(asora::ChemStats), st));
+    asora::ChemArgs A;
+    A.ndens = ndens_dev; A.temp = temp_dev; A.xh = xh_dev; A.phi_ion = phi_ion_dev; A.clump = clump_dev;
+    A.xh_av = xh_av_dev; A.xh_intermed = xh_intermed_dev; A.stats = stats;
+    A.ncell = (long long)m1 * m1 * m1;
+    A.dt = dt; A.bh00 = bh00; A.albpow = albpow; A.colh0 = colh0; A.temph0 = temph0; A.abu_c = abu_c;
+    const long long want = (A.ncell + asora::CHEM_THREADS - 1) / asora::CHEM_THREADS;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)S.num_cu * 16));
+    hipLaunchKernelGGL(asora::chemistry_kernel, dim3(grid), dim3(asora::CHEM_THREADS), 0, st, A);
+    HIP_TRY(hipGetLastError());
+    if (conv_flag || sum_xh1 || sum_xh0) {
+        HIP_TRY(hipMemcpyAsync(landing, stats, sizeof(asora::ChemStats), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (conv_flag) *conv_flag = (long long)landing->conv_flag;
+        if (sum_xh1) *sum_xh1 = landing->sum_xh1;
+        if (sum_xh0) *sum_xh0 = landing->sum_xh0;
+    }
+    return 0;
+}
+
 int asora_global_pass_dev(double dt, const double *ndens_dev, const double *temp_dev, const double *xh_dev,
                           double *xh_av_dev, double *xh_intermed_dev, const double *phi_ion_dev,
                           const double *clump_dev, double bh00, double albpow, double colh0, double temph0,
@@ -882,27 +911,11 @@ int asora_global_pass_dev(double dt, const double *ndens_dev, const double *temp
     if (!ndens_dev || !temp_dev || !xh_dev || !xh_av_dev || !xh_intermed_dev || !phi_ion_dev || !clump_dev)
         return fail(9, "asora_global_pass_dev: null grid pointer");
     ASORA_ON_DEVICE("asora_global_pass_dev");
-    hipStream_t st = (hipStream_t)stream;
     if (!S.chem_stats) HIP_TRY(hipMalloc(&S.chem_stats, sizeof(asora::ChemStats)));
-    HIP_TRY(hipMemsetAsync(S.chem_stats, 0, sizeof(asora::ChemStats), st));
-    asora::ChemArgs A;
-    A.ndens = ndens_dev; A.temp = temp_dev; A.xh = xh_dev; A.phi_ion = phi_ion_dev; A.clump = clump_dev;
-    A.xh_av = xh_av_dev; A.xh_intermed = xh_intermed_dev; A.stats = S.chem_stats;
-    A.ncell = (long long)m1 * m1 * m1;
-    A.dt = dt; A.bh00 = bh00; A.albpow = albpow; A.colh0 = colh0; A.temph0 = temph0; A.abu_c = abu_c;
-    const long long want = (A.ncell + asora::CHEM_THREADS - 1) / asora::CHEM_THREADS;
-    const int grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)S.num_cu * 16));
-    hipLaunchKernelGGL(asora::chemistry_kernel, dim3(grid), dim3(asora::CHEM_THREADS), 0, st, A);
-    HIP_TRY(hipGetLastError());
-    if (conv_flag || sum_xh1 || sum_xh0) {
-        asora::ChemStats h;
-        HIP_TRY(hipMemcpyAsync(&h, S.chem_stats, sizeof h, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (conv_flag) *conv_flag = (long long)h.conv_flag;
-        if (sum_xh1) *sum_xh1 = h.sum_xh1;
-        if (sum_xh0) *sum_xh0 = h.sum_xh0;
-    }
-    return 0;
+    asora::ChemStats h;
+    return global_pass_launch(dt, ndens_dev, temp_dev, xh_dev, xh_av_dev, xh_intermed_dev, phi_ion_dev, clump_dev, bh00,
+                              albpow, colh0, temph0, abu_c, m1, conv_flag, sum_xh1, sum_xh0, (hipStream_t)stream,
+                              S.chem_stats, &h);
 }
 
 int asora_global_pass(double dt, const double *ndens, const double *temp, const double *xh, double *xh_av,

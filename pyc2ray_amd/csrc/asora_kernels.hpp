@@ -733,6 +733,7 @@ void sweep_tab_kernel(SweepArgs A) {
         const double flux = A.src_flux[src];
         const double *__restrict__ nhi = (axis == 0) ? A.nhiB : A.nhiA;
         const double *__restrict__ rnhi = (axis == 0) ? A.rnhiB : A.rnhiA;
+        (void)rnhi;
         double *__restrict__ phi = (axis == 0) ? A.phiB : A.phiA;
         double *__restrict__ heat = (axis == 0) ? A.heatB : A.heatA;
         double *__restrict__ cdh = (src == A.cdh_src) ? ((axis == 0) ? A.cdhB : A.cdhA) : nullptr;

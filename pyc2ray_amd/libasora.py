@@ -238,7 +238,8 @@ def global_pass_dev(dt, ndens_ptr, temp_ptr, xh_ptr, xh_av_ptr, xh_intermed_ptr,
     (asynchronous) when ``want_stats`` is false."""
     cf, s1, s0 = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
     out = (C.byref(cf), C.byref(s1), C.byref(s0)) if want_stats else (None, None, None)
-    _check(_lib.asora_global_pass_dev(float(dt), *[C.c_void_p(p) for p in (ndens_ptr, temp_ptr, xh_ptr, xh_av_ptr,
+    fn = _lib.asora_global_pass_dev
+    _check(fn(float(dt), *[C.c_void_p(p) for p in (ndens_ptr, temp_ptr, xh_ptr, xh_av_ptr,
                                                                            xh_intermed_ptr, phi_ion_ptr, clump_ptr)],
                                       float(bh00), float(albpow), float(colh0), float(temph0), float(abu_c), int(m1),
                                       *out, C.c_void_p(stream or None)))
