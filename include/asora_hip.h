@@ -107,6 +107,22 @@ int asora_global_pass_dev(double dt, const double *ndens_dev, const double *temp
                           double abu_c, int m1, long long *conv_flag, double *sum_xh1, double *sum_xh0,
                           void *stream);
 
+/* The one entry point that ALLOCATES NOTHING.  No counterpart in the reference.  It is for callers that cannot
+ * call hipMalloc while they run: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation.  Same arguments, results and kernel as asora_global_pass_dev, but the kernel's reduction record
+ * (convergence counter + the two sums) lives in a file-scope device array of ASORA_NOALLOC_SCRATCH_BYTES = 256
+ * bytes that each GPU holds from library load to process end (its per-device address is taken once, in
+ * asora_device_init), and the results land in a page-locked buffer made at init: the call itself performs no
+ * hipMalloc / hipFree / hipHostMalloc and no allocating library routine.  Mesh sizes above ASORA_NOALLOC_MAX_M1
+ * are refused with an error.  All calls on one GPU share that GPU's scratch record (cleared at the start of every
+ * call): calls that overlap on one GPU -- different streams or threads -- race on it; serialise them. */
+#define ASORA_NOALLOC_MAX_M1 1024
+int asora_global_pass_dev_noalloc(double dt, const double *ndens_dev, const double *temp_dev, const double *xh_dev,
+                                  double *xh_av_dev, double *xh_intermed_dev, const double *phi_ion_dev,
+                                  const double *clump_dev, double bh00, double albpow, double colh0, double temph0,
+                                  double abu_c, int m1, long long *conv_flag, double *sum_xh1, double *sum_xh0,
+                                  void *stream);
+
 /* replaces asoratest::cinterp_gpu, src/asora/tests.cu:30-59 (Python module libasoratest.cinterp,
  * python_test_module.cu): for the 4x4x4 block of offsets (i,j,k) in [0,4)^3 from pos0, column density
  * and path from the short-characteristics interpolation on `dens` (N^3 doubles, used as the

@@ -18,9 +18,21 @@
 
 #include "../../include/asora_hip.h"
 
+// Scratch of asora_global_pass_dev_noalloc (the entry point that allocates nothing): the chemistry kernel's
+// reduction record (asora::ChemStats: convergence counter + two sums, 24 bytes) lives in this file-scope device
+// array instead of a hipMalloc'ed one.  Each GPU the library runs on holds its own copy until the process ends.
+// In host code the NAME below is only a stand-in for the symbol: the memory is reached through the per-device
+// pointer that hipGetSymbolAddress returns (noalloc_scratch_ptr, set in asora_device_init), never through the name.
+#define ASORA_NOALLOC_SCRATCH_BYTES 256
+static __device__ __align__(256) unsigned char asora_noalloc_scratch[ASORA_NOALLOC_SCRATCH_BYTES];
+
 namespace {
 
 std::string g_err;
+
+constexpr int MAX_DEVICES = 64;
+void *noalloc_scratch_ptr[MAX_DEVICES] = {nullptr};  // device address of asora_noalloc_scratch on each device
+static_assert(sizeof(asora::ChemStats) <= ASORA_NOALLOC_SCRATCH_BYTES, "scratch too small");
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -93,6 +105,7 @@ struct State {
     size_t gscratch_bytes = 0;
     // chemistry pass: reduction results, and grid staging for the host-pointer entry point (lazy)
     asora::ChemStats *chem_stats = nullptr;
+    asora::ChemStats *chem_stats_pinned = nullptr;  // page-locked landing buffer of the no-alloc entry point (made at init)
     double *chem_buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // timing / launch info
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -134,6 +147,20 @@ inline uint32_t wrapped(int32_t v, int N) {
     return (uint32_t)(r < 0 ? r + N : r);
 }
 constexpr int32_t MAX_SOURCE_COORD = 1 << 24;  // |coordinate| bound: keeps every int / double conversion on the path exact
+
+// Set-up of the entry point that allocates nothing, once per device, with that device current (called from
+// asora_device_init): the device address of THIS device's copy of the scratch array -- each GPU holds its own copy
+// at its own address -- and a page-locked landing buffer for the three results.  (A plain host function on
+// purpose: the reference to the array must be seen as a host-side use of the symbol.)
+int noalloc_setup(int dev) {
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(1, "asora_device_init: device index %d beyond %d", dev, MAX_DEVICES);
+    void *p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(asora_noalloc_scratch)));
+    if (!p) return fail(1, "asora_device_init: no device address for the scratch array");
+    noalloc_scratch_ptr[dev] = p;
+    HIP_TRY(hipHostMalloc((void **)&S.chem_stats_pinned, sizeof(asora::ChemStats), hipHostMallocDefault));
+    return 0;
+}
 
 void free_ptr(double *&p) {
     if (p) (void)hipFree(p);
@@ -729,6 +756,7 @@ int asora_device_init(int N, int num_src_par, int mpi_rank, int num_gpus) {
         HIP_TRY(hipEventCreate(&S.ev1));
         // set-up of the entry point that allocates nothing: this device's copy of the scratch array (each GPU holds
         // its own, at its own address) and a page-locked landing buffer for its three results
+        if (int rc2 = noalloc_setup(dev)) return rc2;
         return 0;
     }();
     if (rc) {  // any failure after the first allocation: give everything back, keep the message
@@ -758,6 +786,8 @@ int asora_device_close(void) {
     S.src_pos = nullptr;
     if (S.chem_stats) (void)hipFree(S.chem_stats);
     S.chem_stats = nullptr;
+    if (S.chem_stats_pinned) (void)hipHostFree(S.chem_stats_pinned);
+    S.chem_stats_pinned = nullptr;
     for (double *&b : S.chem_buf) free_ptr(b);
     free_geometry();
     if (S.ev0) (void)hipEventDestroy(S.ev0);
@@ -916,6 +946,27 @@ int asora_global_pass_dev(double dt, const double *ndens_dev, const double *temp
     return global_pass_launch(dt, ndens_dev, temp_dev, xh_dev, xh_av_dev, xh_intermed_dev, phi_ion_dev, clump_dev, bh00,
                               albpow, colh0, temph0, abu_c, m1, conv_flag, sum_xh1, sum_xh0, (hipStream_t)stream,
                               S.chem_stats, &h);
+}
+
+int asora_global_pass_dev_noalloc(double dt, const double *ndens_dev, const double *temp_dev, const double *xh_dev,
+                                  double *xh_av_dev, double *xh_intermed_dev, const double *phi_ion_dev,
+                                  const double *clump_dev, double bh00, double albpow, double colh0, double temph0,
+                                  double abu_c, int m1, long long *conv_flag, double *sum_xh1, double *sum_xh0,
+                                  void *stream) {
+    if (!S.init) return fail(2, "asora_global_pass_dev_noalloc: device not initialised (call asora_device_init)");
+    if (m1 < 1) return fail(9, "asora_global_pass_dev_noalloc: bad mesh size %d", m1);
+    if (m1 > ASORA_NOALLOC_MAX_M1)
+        return fail(14, "asora_global_pass_dev_noalloc: mesh size %d exceeds the maximum of %d this entry point accepts",
+                    m1, ASORA_NOALLOC_MAX_M1);
+    if (!ndens_dev || !temp_dev || !xh_dev || !xh_av_dev || !xh_intermed_dev || !phi_ion_dev || !clump_dev)
+        return fail(9, "asora_global_pass_dev_noalloc: null grid pointer");
+    ASORA_ON_DEVICE("asora_global_pass_dev_noalloc");
+    // this device's copy of the scratch array, by the address taken at init -- never by the array's name
+    asora::ChemStats *stats = static_cast<asora::ChemStats *>(noalloc_scratch_ptr[S.device]);
+    if (!stats || !S.chem_stats_pinned) return fail(2, "asora_global_pass_dev_noalloc: scratch not set up on device %d", S.device);
+    return global_pass_launch(dt, ndens_dev, temp_dev, xh_dev, xh_av_dev, xh_intermed_dev, phi_ion_dev, clump_dev, bh00,
+                              albpow, colh0, temph0, abu_c, m1, conv_flag, sum_xh1, sum_xh0, (hipStream_t)stream, stats,
+                              S.chem_stats_pinned);
 }
 
 int asora_global_pass(double dt, const double *ndens, const double *temp, const double *xh, double *xh_av,

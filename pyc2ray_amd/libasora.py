@@ -58,6 +58,8 @@ ABI = {
     "asora_global_pass": (C.c_int, [C.c_double] + [_dp] * 7 + [C.c_double] * 5 + [C.c_int, C.POINTER(C.c_int)]),
     "asora_global_pass_dev": (C.c_int, [C.c_double] + [C.c_void_p] * 7 + [C.c_double] * 5 +
                               [C.c_int, C.POINTER(C.c_longlong), _dp, _dp, C.c_void_p]),
+    "asora_global_pass_dev_noalloc": (C.c_int, [C.c_double] + [C.c_void_p] * 7 + [C.c_double] * 5 +
+                                      [C.c_int, C.POINTER(C.c_longlong), _dp, _dp, C.c_void_p]),
     "asora_test_cinterp": (C.c_int, [_ip, _dp, C.c_int, _dp, C.c_int]),
     "asora_test_cinterp_ex": (C.c_int, [_ip, _dp, C.c_int, C.c_double, C.c_int, C.c_int, _dp, C.c_int]),
     "asora_visit_count": (C.c_int, [C.c_double, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
@@ -232,13 +234,14 @@ def global_pass(dt, ndens, temp, xh, xh_av, xh_intermed, phi_ion, clump, bh00, a
 
 
 def global_pass_dev(dt, ndens_ptr, temp_ptr, xh_ptr, xh_av_ptr, xh_intermed_ptr, phi_ion_ptr, clump_ptr, bh00,
-                    albpow, colh0, temph0, abu_c, m1, stream=0, want_stats=True):
+                    albpow, colh0, temph0, abu_c, m1, stream=0, want_stats=True, noalloc=False):
     """Chemistry pass on device grids (integers = device addresses).  Returns
     ``(conv_flag, sum(xh_intermed), sum(1 - xh_intermed))`` after waiting for the stream, or ``None``
-    (asynchronous) when ``want_stats`` is false."""
+    (asynchronous) when ``want_stats`` is false.  ``noalloc=True`` goes through ``asora_global_pass_dev_noalloc``,
+    the entry point that allocates nothing (include/asora_hip.h)."""
     cf, s1, s0 = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
     out = (C.byref(cf), C.byref(s1), C.byref(s0)) if want_stats else (None, None, None)
-    fn = _lib.asora_global_pass_dev
+    fn = _lib.asora_global_pass_dev_noalloc if noalloc else _lib.asora_global_pass_dev
     _check(fn(float(dt), *[C.c_void_p(p) for p in (ndens_ptr, temp_ptr, xh_ptr, xh_av_ptr,
                                                                            xh_intermed_ptr, phi_ion_ptr, clump_ptr)],
                                       float(bh00), float(albpow), float(colh0), float(temph0), float(abu_c), int(m1),

@@ -1,0 +1,42 @@
+"""asora_global_pass_dev_noalloc -- the one entry point that allocates nothing (include/asora_hip.h) -- through the
+C-ABI against asora_global_pass_dev, the entry point it is a variant of: same kernel, reduction record in a
+file-scope device array instead of a hipMalloc'ed one.  Two calls in a row, the second on a SMALLER mesh (the
+scratch keeps the last call's contents: what must start at zero is cleared by the call).  Bar: the two grids the
+pass updates bit-identical, the count of non-converged cells equal, the two sums (f64 atomics, order-free) to 1e-13."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pass(asora, c, noalloc):
+    import torch
+    dev = torch.device("cuda", asora.device_index())
+    t = {k: torch.from_numpy(np.ascontiguousarray(c[k]).ravel().copy()).to(dev)
+         for k in ("ndens", "temp", "xh", "xh_av", "xh_intermed", "phi_ion", "clump")}
+    stats = asora.global_pass_dev(c["dt"], t["ndens"].data_ptr(), t["temp"].data_ptr(), t["xh"].data_ptr(),
+                                  t["xh_av"].data_ptr(), t["xh_intermed"].data_ptr(), t["phi_ion"].data_ptr(),
+                                  t["clump"].data_ptr(), c["bh00"], c["albpow"], c["colh0"], c["temph0"], c["abu_c"],
+                                  c["N"], torch.cuda.current_stream(dev).cuda_stream, noalloc=noalloc)
+    return stats, t["xh_av"].cpu().numpy(), t["xh_intermed"].cpu().numpy()
+
+
+def test_noalloc_chemistry_pass_equals_the_allocating_entry_point():
+    from pyc2ray_amd import libasora as asora
+    big, small = cases.chemistry_case(N=40, seed=3), cases.chemistry_case(N=17, seed=8)
+    asora.device_init(40, 8, 0, 1)
+    try:
+        for c in (big, small):  # second call: smaller input, same scratch
+            ref_stats, ref_av, ref_int = run_pass(asora, c, noalloc=False)
+            stats, av, inter = run_pass(asora, c, noalloc=True)
+            assert np.array_equal(av, ref_av) and np.array_equal(inter, ref_int)
+            assert stats[0] == ref_stats[0] and 0 < stats[0] < c["N"] ** 3
+            assert stats[1] == pytest.approx(ref_stats[1], rel=1e-13) and stats[2] == pytest.approx(ref_stats[2], rel=1e-13)
+            assert stats[1] == pytest.approx(float(inter.sum()), rel=1e-12)
+        # sizes beyond the stated maximum are refused with a clear error, before anything is launched
+        with pytest.raises(RuntimeError, match="exceeds the maximum of 1024"):
+            asora.global_pass_dev(1.0, 8, 8, 8, 8, 8, 8, 8, 1.0, 1.0, 1.0, 1.0, 1.0, 1025, noalloc=True)
+    finally:
+        asora.device_close()
