@@ -61,7 +61,6 @@ struct State {
     // grids (N^3 doubles each)
     double *n_dev = nullptr, *x_dev = nullptr;        // density, ionised fraction (host-API staging)
     double *nhiA = nullptr, *nhiB = nullptr;          // neutral density, two layouts
-    double *rnhiA = nullptr, *rnhiB = nullptr;        // its reciprocal, same layouts
     double *phiA = nullptr, *phiB = nullptr;          // rate accumulators, two layouts
     double *heatA = nullptr, *heatB = nullptr;        // lazily allocated
     double *cdhA = nullptr, *cdhB = nullptr;          // lazily allocated
@@ -83,7 +82,6 @@ struct State {
     asora::PlaneInfo *planes_dev = nullptr;
     uint2 *cell_meta_dev = nullptr;
     double2 *cell_geo_dev = nullptr;
-    double *cell_rvol_dev = nullptr;
     int geo_N = 0, geo_nplanes = 0, geo_entries = 0, geo_vmap[8] = {0}, geo_nmax_rate = 0;
     double geo_R = -1.0, geo_dr = -1.0;
     bool geo_valid = false;
@@ -207,8 +205,7 @@ void free_geometry() {
     if (S.planes_dev) (void)hipFree(S.planes_dev);
     if (S.cell_meta_dev) (void)hipFree(S.cell_meta_dev);
     if (S.cell_geo_dev) (void)hipFree(S.cell_geo_dev);
-    if (S.cell_rvol_dev) (void)hipFree(S.cell_rvol_dev);
-    S.planes_dev = nullptr; S.cell_meta_dev = nullptr; S.cell_geo_dev = nullptr; S.cell_rvol_dev = nullptr;
+    S.planes_dev = nullptr; S.cell_meta_dev = nullptr; S.cell_geo_dev = nullptr;
     S.geo_valid = false;
 }
 
@@ -248,7 +245,6 @@ struct HostGeometry {
     std::vector<asora::PlaneInfo> planes;  // [variant][nplanes]
     std::vector<uint2> meta;
     std::vector<double2> geo;
-    std::vector<double> rvol;  // 1 / vol_ph, IEEE division (this file is compiled without contraction)
     int vmap[8] = {0};
     int nplanes = 0, nvariants = 0, entries_max = 0;
 };
@@ -310,7 +306,6 @@ void make_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
                         gq.y = dist2 * pd * asora::FOURPI;
                         meta.push_back(m);
                         geo.push_back(gq);
-                        G.rvol.push_back(1.0 / gq.y);
                     }
                 }
                 if (pass == 0) pl[n].cntA = (uint32_t)meta.size() - pl[n].off;
@@ -318,7 +313,7 @@ void make_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
             pl[n].cntT = (uint32_t)meta.size() - pl[n].off;
         }
     }
-    if (meta.empty()) { meta.push_back(uint2{0, 0}); geo.push_back(double2{0, 0}); G.rvol.push_back(0.0); }
+    if (meta.empty()) { meta.push_back(uint2{0, 0}); geo.push_back(double2{0, 0}); }
     G.nplanes = nplanes;
     G.nvariants = (int)keys.size();
     G.entries_max = entries_max;
@@ -333,12 +328,10 @@ int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
     HIP_TRY(hipMalloc(&S.planes_dev, G.planes.size() * sizeof(asora::PlaneInfo)));
     HIP_TRY(hipMalloc(&S.cell_meta_dev, G.meta.size() * sizeof(uint2)));
     HIP_TRY(hipMalloc(&S.cell_geo_dev, G.geo.size() * sizeof(double2)));
-    HIP_TRY(hipMalloc(&S.cell_rvol_dev, G.rvol.size() * sizeof(double)));
     // synchronous copies: the host vectors die at the end of this function
     HIP_TRY(hipMemcpy(S.planes_dev, G.planes.data(), G.planes.size() * sizeof(asora::PlaneInfo), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(S.cell_meta_dev, G.meta.data(), G.meta.size() * sizeof(uint2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(S.cell_geo_dev, G.geo.data(), G.geo.size() * sizeof(double2), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(S.cell_rvol_dev, G.rvol.data(), G.rvol.size() * sizeof(double), hipMemcpyHostToDevice));
     for (int i = 0; i < 8; i++) S.geo_vmap[i] = G.vmap[i];
     S.geo_nmax_rate = 0;
     for (size_t i = 0; i < G.planes.size(); i++)
@@ -470,7 +463,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     }
 
     const dim3 tb(32, 8), tg((N + 31) / 32, (N + 31) / 32, N);
-    hipLaunchKernelGGL(asora::prep_nhi_kernel, tg, tb, 0, st, S.n_dev, xh_dev, S.nhiA, S.nhiB, S.rnhiA, S.rnhiB, N);
+    hipLaunchKernelGGL(asora::prep_nhi_kernel, tg, tb, 0, st, S.n_dev, xh_dev, S.nhiA, S.nhiB, N);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(S.phiA, 0, bytes, st));
     HIP_TRY(hipMemsetAsync(S.phiB, 0, bytes, st));
@@ -485,7 +478,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
 
     asora::SweepArgs A;
     std::memset(&A, 0, sizeof A);
-    A.nhiA = S.nhiA; A.nhiB = S.nhiB; A.rnhiA = S.rnhiA; A.rnhiB = S.rnhiB; A.phiA = S.phiA; A.phiB = S.phiB;
+    A.nhiA = S.nhiA; A.nhiB = S.nhiB; A.phiA = S.phiA; A.phiB = S.phiB;
     A.heatA = want_heat ? S.heatA : nullptr; A.heatB = want_heat ? S.heatB : nullptr;
     A.cdhA = want_cdh ? S.cdhA : nullptr; A.cdhB = want_cdh ? S.cdhB : nullptr;
     A.src_pos = S.src_pos; A.src_flux = S.src_flux;
@@ -520,7 +513,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     int qshift = 0;
     if (use_tab) {
         // ONE packed array of (column density, weight) pairs, updated in place, + per-row/column tables
-        A.planes = S.planes_dev; A.cell_meta = S.cell_meta_dev; A.cell_geo = S.cell_geo_dev; A.cell_rvol = S.cell_rvol_dev;
+        A.planes = S.planes_dev; A.cell_meta = S.cell_meta_dev; A.cell_geo = S.cell_geo_dev;
         A.nplanes = S.geo_nplanes; A.cw_entries = S.geo_entries;
         A.rate_only = S.skip_unobserved ? 1 : 0; A.nmax_rate = S.geo_nmax_rate;
         for (int i = 0; i < 8; i++) A.vmap[i] = S.geo_vmap[i];
@@ -741,7 +734,7 @@ int asora_device_init(int N, int num_src_par, int mpi_rank, int num_gpus) {
     }
     S.init = true;  // from here on asora_device_close releases whatever exists
     const int rc = [&]() -> int {
-        double **grids[] = {&S.n_dev, &S.x_dev, &S.nhiA, &S.nhiB, &S.rnhiA, &S.rnhiB, &S.phiA, &S.phiB};
+        double **grids[] = {&S.n_dev, &S.x_dev, &S.nhiA, &S.nhiB, &S.phiA, &S.phiB};
         for (double **g : grids) {
             hipError_t e = hipMalloc(g, S.cells * sizeof(double));
             if (e != hipSuccess)
@@ -778,7 +771,7 @@ int asora_device_close(void) {
     if (!S.init) return fail(2, "asora_device_close: device not initialised");
     ASORA_ON_DEVICE("asora_device_close");
     (void)hipDeviceSynchronize();
-    double **grids[] = {&S.n_dev, &S.x_dev, &S.nhiA, &S.nhiB, &S.rnhiA, &S.rnhiB, &S.phiA, &S.phiB, &S.heatA, &S.heatB, &S.cdhA,
+    double **grids[] = {&S.n_dev, &S.x_dev, &S.nhiA, &S.nhiB, &S.phiA, &S.phiB, &S.heatA, &S.heatB, &S.cdhA,
                         &S.cdhB, &S.out0, &S.out1, &S.out2, &S.thin, &S.thick, &S.hthin, &S.hthick,
                         &S.src_flux, &S.gscratch, &S.log10_table};
     for (double **g : grids) free_ptr(*g);

@@ -66,7 +66,6 @@ constexpr int PLANE_INFO_DOUBLES = sizeof(PlaneInfo) / sizeof(double);
 struct SweepArgs {
     const double *nhiA;  // nHI, [i][j][k]
     const double *nhiB;  // nHI, [i][k][j]
-    const double *rnhiA, *rnhiB;  // 1 / nHI (correctly rounded, prep_nhi_kernel), same two layouts
     double *phiA, *phiB;    // rate accumulators in the two layouts
     double *heatA, *heatB;  // heating accumulators (HEAT only)
     double *cdhA, *cdhB;    // column density of source `cdh_src` in the two layouts (may be null)
@@ -89,7 +88,6 @@ struct SweepArgs {
     const uint2 *cell_meta;    // .x = a | b << 10 | flags << 20, .y = staging position of (a-1,b-1) | of (a,b-1) << 16;
                                // list A (rate-producing) then list B per plane
     const double2 *cell_geo;   // {path * dr, vol_ph = dist2 * (path*dr) * 4pi}
-    const double *cell_rvol;   // 1 / vol_ph, correctly rounded (host)
     int nplanes;
     int cw_entries;            // staged (column density, weight) pairs per task (max over variants)
     int wtab;                  // rows/columns per plane (max) = entries of the per-row / per-column LDS tables
@@ -216,21 +214,6 @@ __device__ __forceinline__ RatePrep rates_prepare(const SweepArgs &A, Log10LDS l
     r.Lout = table_index(tau_out, A.minlogtau, A.dlogtau, A.rdlogtau, A.num_tau, lg);
     return r;
 }
-// The same with the two quotients that have a table-known divisor -- flux / vol_ph (vol_ph: geometry table) and
-// rate / nHI (nHI: grid) -- formed from the divisor's correctly rounded reciprocal (host / prep_nhi_kernel: one IEEE
-// division per table entry / grid cell instead of one per visit) by Markstein's correction step, div_const: 3 full-rate
-// instructions instead of v_rcp_f64 (quarter rate) + 7; bit-identical to `/` (asora_test_division on the device).
-__device__ __forceinline__ RatePrep rates_prepare_rcp(const SweepArgs &A, Log10LDS lg, double flux, double cdh_in,
-                                                      double cdh_out, double vol_ph, double rvol) {
-    RatePrep r;
-    const double tau_in = cdh_in * A.sig;
-    const double tau_out = cdh_out * A.sig;
-    r.prefact = div_const(flux, vol_ph, rvol);
-    r.dtau = tau_out - tau_in;
-    r.Lin = table_index(tau_in, A.minlogtau, A.dlogtau, A.rdlogtau, A.num_tau, lg);
-    r.Lout = table_index(tau_out, A.minlogtau, A.dlogtau, A.rdlogtau, A.num_tau, lg);
-    return r;
-}
 __device__ __forceinline__ double2 table_pair(const double *__restrict__ t, int i0) {
     const char *p = reinterpret_cast<const char *>(t) + (uint32_t)i0 * 8u;  // SGPR base + 32-bit offset
     double2 v;
@@ -250,9 +233,9 @@ __device__ __forceinline__ RateLoads rates_load(const SweepArgs &A, const RatePr
     return l;
 }
 __device__ __forceinline__ double pair_eval(double2 t, double residual) { return t.x + residual * (t.y - t.x); }
-template <bool HEAT, bool RCP = false>
+template <bool HEAT>
 __device__ __forceinline__ void rates_finish(const SweepArgs &A, const RatePrep &r, const RateLoads &l, double nHI,
-                                             double &phi, double &heat, double rnhi = 0.0) {
+                                             double &phi, double &heat) {
     const double tau_photo_limit = (double)1.0e-7f;
     const bool thick = fabs(r.dtau) > tau_photo_limit;
     const double phi_in = r.prefact * pair_eval(l.thick_in, r.Lin.residual);
@@ -269,8 +252,8 @@ __device__ __forceinline__ void rates_finish(const SweepArgs &A, const RatePrep 
             h = thick ? h : h_thin;
         }
     }
-    phi = RCP ? div_const(p, nHI, rnhi) : div_exact(p, nHI);
-    if (HEAT) heat = RCP ? div_const(h, nHI, rnhi) : div_exact(h, nHI);
+    phi = div_exact(p, nHI);
+    if (HEAT) heat = div_exact(h, nHI);
 }
 
 // raytracing.f90:807-813
@@ -732,8 +715,6 @@ void sweep_tab_kernel(SweepArgs A) {
         else { p0 = i0; u0 = j0; v0 = k0; ur1 = j0r + 1; vr1 = k0r + 1; }
         const double flux = A.src_flux[src];
         const double *__restrict__ nhi = (axis == 0) ? A.nhiB : A.nhiA;
-        const double *__restrict__ rnhi = (axis == 0) ? A.rnhiB : A.rnhiA;
-        (void)rnhi;
         double *__restrict__ phi = (axis == 0) ? A.phiB : A.phiA;
         double *__restrict__ heat = (axis == 0) ? A.heatB : A.heatA;
         double *__restrict__ cdh = (src == A.cdh_src) ? ((axis == 0) ? A.cdhB : A.cdhA) : nullptr;
@@ -811,14 +792,12 @@ void sweep_tab_kernel(SweepArgs A) {
         double2 geo_c[P], geo_n[P];
         double nhi_c[P], nhi_n[P];
         uint32_t g_c[P], g_n[P];
-        uint32_t idx_c[P];  // table index of the current phase's cells (for the in-phase reciprocal loads)
         {
             const uint32_t baseP = (uint32_t)wrap(p0 + sp * d0.n, N) * strideP;
 #pragma unroll
             for (int q = 0; q < P; q++) {
                 bool v, ia;
                 const uint32_t idx = slot_index<NW, QS>(d0, wave, q, lane, v, ia);
-                idx_c[q] = d0.off + idx;
                 const uint32_t a = meta_c[q].x & META_COORD_MASK, b = (meta_c[q].x >> META_COORD_BITS) & META_COORD_MASK;
                 g_c[q] = baseP + (uint32_t)rowU[set_u + a] + (uint32_t)colV[set_v + b];
                 geo_c[q] = at_byte(A.cell_geo, (d0.off + idx) * 16u);
@@ -932,17 +911,6 @@ void sweep_tab_kernel(SweepArgs A) {
                     nhi_n[q] = at_byte(nhi, g_n[q] * 8u);
                 }
             }
-#ifdef ASORA_RCP_TABLES
-            // reciprocals of THIS phase's divisors (1 / vol_ph, 1 / nHI): only the rates need them, so they are
-            // loaded here rather than carried across the phase boundary (registers); they are consumed behind the
-            // rates' table look-ups, which are younger and waited for anyway
-            double rv_c[P], rn_c[P];
-#pragma unroll
-            for (int q = 0; q < P; q++) {
-                rv_c[q] = at_byte(A.cell_rvol, idx_c[q] * 8u);
-                rn_c[q] = at_byte(rnhi, g_c[q] * 8u);
-            }
-#endif
             __builtin_amdgcn_s_setprio(2);
             // rates: when every slot of the wave holds rate-producing cells, all of them together (their log10 /
             // look-up chains interleave); otherwise one slot at a time
@@ -950,22 +918,13 @@ void sweep_tab_kernel(SweepArgs A) {
                 RatePrep rp[P];
                 RateLoads rl[P];
 #pragma unroll
-                for (int q = 0; q < P; q++)
-#ifdef ASORA_RCP_TABLES
-                    rp[q] = rates_prepare_rcp(A, C.lg, flux, cin[q], cdo[q], geo_c[q].y, rv_c[q]);
-#else
-                    rp[q] = rates_prepare(A, C.lg, flux, cin[q], cdo[q], geo_c[q].y);
-#endif
+                for (int q = 0; q < P; q++) rp[q] = rates_prepare(A, C.lg, flux, cin[q], cdo[q], geo_c[q].y);
 #pragma unroll
                 for (int q = 0; q < P; q++) rl[q] = rates_load<HEAT>(A, rp[q]);
 #pragma unroll
                 for (int q = 0; q < P; q++) {
                     double p_, h_ = 0.0;
-#ifdef ASORA_RCP_TABLES
-                    rates_finish<HEAT, true>(A, rp[q], rl[q], nhi_c[q], p_, h_, rn_c[q]);
-#else
                     rates_finish<HEAT>(A, rp[q], rl[q], nhi_c[q], p_, h_);
-#endif
                     ph[q] = p_;
                     if (HEAT) ht[q] = h_;
                 }
@@ -973,18 +932,10 @@ void sweep_tab_kernel(SweepArgs A) {
 #pragma unroll
                 for (int q = 0; q < P; q++)
                     if (rate_slot[q]) {
-#ifdef ASORA_RCP_TABLES
-                        const RatePrep rp = rates_prepare_rcp(A, C.lg, flux, cin[q], cdo[q], geo_c[q].y, rv_c[q]);
-#else
                         const RatePrep rp = rates_prepare(A, C.lg, flux, cin[q], cdo[q], geo_c[q].y);
-#endif
                         const RateLoads rl = rates_load<HEAT>(A, rp);
                         double p_, h_ = 0.0;
-#ifdef ASORA_RCP_TABLES
-                        rates_finish<HEAT, true>(A, rp, rl, nhi_c[q], p_, h_, rn_c[q]);
-#else
                         rates_finish<HEAT>(A, rp, rl, nhi_c[q], p_, h_);
-#endif
                         ph[q] = p_;
                         if (HEAT) ht[q] = h_;
                     }
@@ -1020,7 +971,6 @@ void sweep_tab_kernel(SweepArgs A) {
 #pragma unroll
             for (int q = 0; q < P; q++) {
                 meta_c[q] = meta_n[q];
-                idx_c[q] = idx_n[q];
                 geo_c[q] = geo_n[q];
                 nhi_c[q] = nhi_n[q];
                 g_c[q] = g_n[q];
@@ -1035,8 +985,7 @@ void sweep_tab_kernel(SweepArgs A) {
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prep_nhi_kernel(const double *__restrict__ ndens,
                                                        const double *__restrict__ xh, double *__restrict__ nhiA,
-                                                       double *__restrict__ nhiB, double *__restrict__ rnhiA,
-                                                       double *__restrict__ rnhiB, int N) {
+                                                       double *__restrict__ nhiB, int N) {
     __shared__ double tile[32][33];
     const size_t slab = (size_t)blockIdx.z * N * N;
     const int k = blockIdx.x * 32 + threadIdx.x;
@@ -1046,7 +995,6 @@ __global__ __launch_bounds__(256) void prep_nhi_kernel(const double *__restrict_
             const size_t id = slab + (size_t)j * N + k;
             const double v = ndens[id] * (1.0 - xh[id]);
             nhiA[id] = v;
-            rnhiA[id] = 1.0 / v;  // IEEE division: the reciprocal the sweep's rate / nHI quotient is corrected from
             tile[r][threadIdx.x] = v;
         }
     }
@@ -1054,11 +1002,7 @@ __global__ __launch_bounds__(256) void prep_nhi_kernel(const double *__restrict_
     const int j2 = blockIdx.y * 32 + threadIdx.x;
     for (int r = threadIdx.y; r < 32; r += 8) {
         const int k2 = blockIdx.x * 32 + r;
-        if (j2 < N && k2 < N) {
-            const double v = tile[threadIdx.x][r];
-            nhiB[slab + (size_t)k2 * N + j2] = v;
-            rnhiB[slab + (size_t)k2 * N + j2] = 1.0 / v;
-        }
+        if (j2 < N && k2 < N) nhiB[slab + (size_t)k2 * N + j2] = tile[threadIdx.x][r];
     }
 }
 
