@@ -165,7 +165,8 @@ int asora_last_sweep_ms(float *ms);
 
 /* Launch geometry of the last sweep (for profile matching): workgroups, threads per workgroup, dynamic LDS
  * bytes per workgroup, and where the staged column densities lived: 0 global scratch, 1 LDS as (column
- * density, weight) pairs, 2 LDS as column densities only; +4 * log2(sectors per workgroup) when the four-quadrant / eight-octant kernel ran. */
+ * density, weight) pairs, 2 LDS as column densities only; +4 * log2(sectors per workgroup) when the four-quadrant /
+ * eight-octant kernel ran; +16 * log2(sources per workgroup) when it took several sources side by side. */
 int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_is_lds);
 
 /* Tuning / test switches: "force_generic" (1: always run the table-free sweep kernel),
@@ -180,6 +181,9 @@ int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_i
  * "quad_max_entries" staged entries per quadrant, default 1210, i.e. R <~ 46 cells; 1: whenever the quadrants share
  * their geometry; 2: eight octants of an axis per workgroup, automatic up to "oct_max_entries", default 64, R <~ 8;
  * -1: never),
+ * "src_pack" (the multi-sector kernels take 1 << src_pack consecutive sources of the sweep order per workgroup, side by
+ * side in the lanes of a wavefront: 0 = automatic, while four 256-thread workgroups of that kind fit on a CU --
+ * "pack_max_lds" bytes each, default 40 KiB, R <~ 12 cells; 2 / 3: four / eight sources; -1: never),
  * "source_order" (see asora_source_order),
  * "skip_unobserved" (1: cells outside the R-sphere -- never upwind of a cell inside it -- are swept only for
  * the source whose column density is exported; phi and coldensh_out unchanged, ~27 % less time at 256^3 / R = 60;

@@ -89,9 +89,13 @@ struct State {
     int lds_pad = 0;              // option "lds_pad": extra dynamic LDS per workgroup (occupancy experiments)
     int wg_threads = 0;           // option "wg_threads": workgroup size of the table-driven kernel, 256/512/1024 (0: automatic)
     int quad_kernel = 0;          // option "quad_kernel": four quadrants per workgroup (0: automatic, 1: whenever possible, -1: never)
-    int oct_max_entries = 64;     // option "oct_max_entries": automatic choice of eight octants per workgroup up to this many entries (R <~ 8)
+    int oct_max_entries = 120;    // option "oct_max_entries": automatic choice of eight octants per workgroup up to this many entries (R <~ 12)
     int quad_max_entries = 1210;  // option "quad_max_entries": automatic choice up to this many staged entries per quadrant (R <~ 46)
     int last_quad = 0;
+    int src_pack = 0;             // option "src_pack": sources per workgroup of the multi-sector kernels as a shift (0: automatic, -1: one, 2: four, 3: eight)
+    int pack_max_lds = 40 * 1024; // option "pack_max_lds": automatic packing only while a workgroup's LDS stays below this (four 256-thread workgroups per CU)
+    int pack_max_entries = 64;    // option "pack_max_entries": ... and up to this many staged entries per sector (R <~ 8)
+    int last_pack = 0;
     int compact_staging = 0;      // option "compact_staging": stage column densities only (0: automatic, 1: always, -1: never)
     int skip_unobserved = 0;      // option "skip_unobserved": cells outside the R-sphere only for the exported column density
     int force_generic = 0;        // option "force_generic": always use the table-free kernel
@@ -340,12 +344,12 @@ int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
     return 0;
 }
 
-template <bool L, bool H, int T, bool WS = true, int QD = 0>
+template <bool L, bool H, int T, bool WS = true, int QD = 0, int SS = 0>
 int launch_sweep_tab(const asora::SweepArgs &A, int grid, size_t lds, hipStream_t st) {
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)asora::sweep_tab_kernel<L, H, T, WS, QD>,
+        HIP_TRY(hipFuncSetAttribute((const void *)asora::sweep_tab_kernel<L, H, T, WS, QD, SS>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((asora::sweep_tab_kernel<L, H, T, WS, QD>), dim3(grid), dim3(T), lds, st, A);
+    hipLaunchKernelGGL((asora::sweep_tab_kernel<L, H, T, WS, QD, SS>), dim3(grid), dim3(T), lds, st, A);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -485,6 +489,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     A.thick = S.thick; A.thin = S.thin; A.hthick = S.hthick; A.hthin = S.hthin;
     A.log10_table = S.log10_table;
     A.ntasks = (long long)asora::SECTORS * num_src;  // (a quarter of that for the four-quadrant kernel, set below)
+    A.nsrc = num_src;
     A.src_begin = 0;
     A.cdh_src = want_cdh ? S.staged_last : -1;
     A.N = N;
@@ -510,7 +515,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     }
     size_t lds_stage, lds_stage_c = 0, lds_fixed;
     bool quad = false;
-    int qshift = 0;
+    int qshift = 0, sshift = 0;
     if (use_tab) {
         // ONE packed array of (column density, weight) pairs, updated in place, + per-row/column tables
         A.planes = S.planes_dev; A.cell_meta = S.cell_meta_dev; A.cell_geo = S.cell_geo_dev;
@@ -528,11 +533,14 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         if (quad && A.q_max <= std::min(A.last_l, A.last_r) &&
             (S.quad_kernel == 2 || (S.quad_kernel == 0 && A.cw_entries <= S.oct_max_entries)))
             qshift = 3;
+        auto lds_need = [&](int qs, int ss, bool q) {
+            const size_t nq = (size_t)1 << qs, nsrc = (size_t)1 << ss, sw = (size_t)(q ? 2 : 1) * A.wtab * nsrc;
+            lds_stage = nsrc * nq * (size_t)A.cw_entries * 2 * sizeof(double);
+            lds_stage_c = nsrc * nq * (size_t)((A.cw_entries + 1) & ~1) * sizeof(double);  // column densities only
+            lds_fixed = (size_t)(5 * sw + (sw & 1) + asora::PLANE_INFO_DOUBLES * A.nplanes + (ss ? nsrc : 0)) * sizeof(double) + lds_log;
+        };
         for (;;) {
-            const size_t nq = (size_t)1 << qshift, sw = (size_t)(quad ? 2 : 1) * A.wtab;
-            lds_stage = nq * (size_t)A.cw_entries * 2 * sizeof(double);
-            lds_stage_c = nq * (size_t)((A.cw_entries + 1) & ~1) * sizeof(double);  // column densities only
-            lds_fixed = (size_t)(5 * sw + (sw & 1) + asora::PLANE_INFO_DOUBLES * A.nplanes) * sizeof(double) + lds_log;
+            lds_need(qshift, 0, quad);
             if (!quad || std::min(lds_stage, S.compact_staging >= 0 ? lds_stage_c : lds_stage) + lds_fixed +
                                  (size_t)S.lds_pad <= (size_t)S.max_lds)
                 break;
@@ -541,7 +549,25 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             if (qshift == 3) qshift = 2;
             else { quad = false; qshift = 0; }
         }
-        if (quad) A.ntasks = (long long)(asora::SECTORS >> qshift) * num_src;
+        // Several consecutive sources of the (curve-sorted) list per workgroup: the smallest radii, whose planes leave
+        // most lanes of a wavefront idle and whose tasks are dominated by their set-up.  256 threads, (column density,
+        // weight) pairs; automatic while four such workgroups fit on a CU (option "pack_max_lds").
+        if (quad && S.src_pack >= 0 && S.compact_staging <= 0 && (S.wg_threads == 0 || S.wg_threads == 256)) {
+            // (measured, 1e4 sources at 256^3, unpacked -> four sources per workgroup: R = 3 0.21 -> 0.13 ms, R = 5 0.30 -> 0.27,
+            // R = 8 0.76 -> 0.66; R = 10 1.08 -> 1.17: from there on a phase of one source keeps the wavefronts busy and
+            // the packed lanes' rate atomics meet in the same cells; eight sources never beat four)
+            for (int ss = (S.src_pack > 0 ? S.src_pack : 2); ss >= 2; ss--) {
+                if (qshift + ss > 6) continue;
+                lds_need(qshift, ss, true);
+                const size_t full = lds_stage + lds_fixed + (size_t)S.lds_pad;
+                // (a forced packing that does not fit in LDS degrades to fewer sources per workgroup)
+                if (S.src_pack > 0 ? full <= (size_t)S.max_lds
+                                   : (full <= (size_t)S.pack_max_lds && A.cw_entries <= S.pack_max_entries &&
+                                      num_src >= (8 << ss))) { sshift = ss; break; }
+            }
+            lds_need(qshift, sshift, true);
+        }
+        if (quad) A.ntasks = (long long)(asora::SECTORS >> qshift) * ((num_src + (1 << sshift) - 1) >> sshift);
     } else {
         lds_stage = 2 * (size_t)A.plane_elems * sizeof(double);  // table-free kernel: two square planes
         lds_fixed = lds_log;
@@ -563,7 +589,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     // 1.25e11 updates/s; equal at R = 80), and the LDS range doubles (R = 140: global 7.2e10 -> 1.04e11,
     // R = 160: 7.0e10 -> 9.9e10; 256^3 full box and 512^3 at R = 150 fit).
     bool compact = false;
-    if (use_tab && S.lds_stage_limit <= 0 && S.compact_staging >= 0 &&
+    if (use_tab && S.lds_stage_limit <= 0 && S.compact_staging >= 0 && !sshift &&  // (the packed kernels stage pairs)
         lds_stage_c + lds_fixed + (size_t)S.lds_pad <= (size_t)S.max_lds &&
         (S.compact_staging > 0 || lds_stage + lds_fixed + (size_t)S.lds_pad > (size_t)S.max_lds / (quad ? 3 : 2) ||
          // two workgroups per CU with pairs, four of 256 threads with column densities only: the latter wins while
@@ -577,7 +603,10 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     int threads = asora::SWEEP_THREADS;
     if (use_tab) {
         const size_t full = lds_stage + lds_fixed + (size_t)S.lds_pad;
-        if (S.wg_threads == 64 || S.wg_threads == 128 || S.wg_threads == 192 || S.wg_threads == 256 ||
+        if (sshift) {  // packed sources: 256 threads, pairs in LDS (checked above)
+            threads = 256;
+            use_lds = true;
+        } else if (S.wg_threads == 64 || S.wg_threads == 128 || S.wg_threads == 192 || S.wg_threads == 256 ||
             S.wg_threads == 512 || S.wg_threads == 1024) {
             threads = S.wg_threads;
             if (compact && threads < 256 && !quad) return fail(13, "asora_do_all_sources: compact staging needs wg_threads >= 256");
@@ -637,7 +666,16 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
 #define ASORA_LAUNCH_QUAD_T(TH) \
     (qshift == 3 ? (compact ? ASORA_LAUNCH_QUAD(TH, false, 3) : ASORA_LAUNCH_QUAD(TH, true, 3)) \
                  : (compact ? ASORA_LAUNCH_QUAD(TH, false, 2) : ASORA_LAUNCH_QUAD(TH, true, 2)))
-            if (quad) {
+#define ASORA_LAUNCH_PACK(QD, SS) \
+    (want_heat ? launch_sweep_tab<true, true, 256, true, QD, SS>(A, grid, lds, st) \
+               : launch_sweep_tab<true, false, 256, true, QD, SS>(A, grid, lds, st))
+            if (quad && sshift) {
+                if (qshift == 3 && sshift == 3) rc = ASORA_LAUNCH_PACK(3, 3);
+                else if (qshift == 3 && sshift == 2) rc = ASORA_LAUNCH_PACK(3, 2);
+                else if (qshift == 2 && sshift == 3) rc = ASORA_LAUNCH_PACK(2, 3);
+                else if (qshift == 2 && sshift == 2) rc = ASORA_LAUNCH_PACK(2, 2);
+                else return fail(13, "asora_do_all_sources: unsupported packing %d/%d", qshift, sshift);
+            } else if (quad) {
                 if (threads == 64) rc = ASORA_LAUNCH_QUAD_T(64);
                 else if (threads == 128) rc = ASORA_LAUNCH_QUAD_T(128);
                 else if (threads == 256) rc = ASORA_LAUNCH_QUAD_T(256);
@@ -656,6 +694,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
 #undef ASORA_LAUNCH_TAB
 #undef ASORA_LAUNCH_QUAD
 #undef ASORA_LAUNCH_QUAD_T
+#undef ASORA_LAUNCH_PACK
         } else {
             if (use_lds) rc = want_heat ? launch_sweep<true, true>(A, grid, lds, st) : launch_sweep<true, false>(A, grid, lds, st);
             else rc = want_heat ? launch_sweep<false, true>(A, grid, lds, st) : launch_sweep<false, false>(A, grid, lds, st);
@@ -664,7 +703,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         HIP_TRY(hipEventRecord(S.ev1, st));
         S.timed = true;
         S.last_grid = grid; S.last_block = use_tab ? threads : asora::SWEEP_THREADS; S.last_lds = (int)lds;
-        S.last_is_lds = (use_lds ? (compact ? 2 : 1) : 0) | (qshift << 2);
+        S.last_is_lds = (use_lds ? (compact ? 2 : 1) : 0) | (qshift << 2) | (sshift << 4);
     }
 
     hipLaunchKernelGGL(asora::finalize_kernel, tg, tb, 0, st, S.phiA, S.phiB, phi_out_dev, N);
@@ -786,7 +825,7 @@ int asora_device_close(void) {
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     State fresh;  // options and the last launch record survive a close
-    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.compact_staging = S.compact_staging; fresh.quad_kernel = S.quad_kernel; fresh.quad_max_entries = S.quad_max_entries; fresh.oct_max_entries = S.oct_max_entries; fresh.last_quad = S.last_quad; fresh.max_table_cells = S.max_table_cells;
+    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.compact_staging = S.compact_staging; fresh.quad_kernel = S.quad_kernel; fresh.quad_max_entries = S.quad_max_entries; fresh.oct_max_entries = S.oct_max_entries; fresh.last_quad = S.last_quad; fresh.src_pack = S.src_pack; fresh.pack_max_lds = S.pack_max_lds; fresh.pack_max_entries = S.pack_max_entries; fresh.max_table_cells = S.max_table_cells;
     fresh.last_tab = S.last_tab; fresh.last_grid = S.last_grid; fresh.last_block = S.last_block;
     fresh.last_lds = S.last_lds; fresh.last_is_lds = S.last_is_lds;
     const int dev = S.device;
@@ -1097,6 +1136,9 @@ int asora_set_option(const char *name, long long value) {
     else if (!std::strcmp(name, "quad_max_entries")) S.quad_max_entries = (int)value;
     else if (!std::strcmp(name, "oct_max_entries")) S.oct_max_entries = (int)value;
     else if (!std::strcmp(name, "compact_staging")) S.compact_staging = (int)value;
+    else if (!std::strcmp(name, "src_pack")) S.src_pack = (int)value;
+    else if (!std::strcmp(name, "pack_max_lds")) S.pack_max_lds = (int)value;
+    else if (!std::strcmp(name, "pack_max_entries")) S.pack_max_entries = (int)value;
     else if (!std::strcmp(name, "skip_unobserved")) S.skip_unobserved = value != 0;
     else return fail(12, "asora_set_option: unknown option '%s'", name);
     return 0;

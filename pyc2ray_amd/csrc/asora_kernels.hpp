@@ -74,7 +74,8 @@ struct SweepArgs {
     const double *thick, *thin, *hthick, *hthin;  // padded tables
     const double *log10_table;                    // LOG10_TABLE_DOUBLES doubles (asora_log10.hpp)
     double *gscratch;       // global staging (when LDS is too small), 2*plane_elems per block
-    long long ntasks;       // 24 * number of sources of this launch
+    long long ntasks;       // 24 * number of sources of this launch (fewer when a workgroup takes several sectors / sources)
+    int nsrc;               // sources of this launch (the packed kernels' last group may be partial)
     int src_begin;          // first source of this launch
     int cdh_src;            // source whose column density is exported (-1: none)
     int N, q_max, last_l, last_r;  // last_l > 0: lowest offset is -last_l
@@ -664,13 +665,22 @@ __device__ __forceinline__ void phase_barrier() {
 // directions (two sets of row / column tables), ownership mask.  Same arithmetic per cell: bit-identical.
 // QSHIFT = 3: the same with all eight sign octants of an axis (both pyramids) per workgroup, for the smallest radii;
 // requires that the box limits bind on neither side (host check), so that both pyramids have the same planes.
-template <bool LDS_STAGE, bool HEAT, int THREADS, bool WSTAGED, int QSHIFT = 0>
+// SSHIFT > 0 (with QUAD / OCT): the workgroup takes 1 << SSHIFT consecutive SOURCES of the (curve-sorted) list side
+// by side as well -- lane l works on quadrant l & (NQ - 1) of source (l >> QSHIFT) & (NSRC - 1) of its group and on
+// cell (chunk * 64 + l) >> (QSHIFT + SSHIFT).  All sources share the geometry tables (same N, R; box limits not
+// binding), so the cell lists, chunks and phases are those of one source with NSRC times the lanes per cell: at
+// R = 5 a plane of one source fills half a wavefront, eight sources fill it, and the per-task set-up (tables, plane
+// list, log10 table, first loads) is paid once per group.  Per (source, quadrant): staging array; per source: row /
+// column / interpolation tables (the interpolation carries the source's own coordinate), flux, position.
+template <bool LDS_STAGE, bool HEAT, int THREADS, bool WSTAGED, int QSHIFT = 0, int SSHIFT = 0>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(ASORA_WAVES_PER_EU, ASORA_WAVES_PER_EU)))
 void sweep_tab_kernel(SweepArgs A) {
     constexpr int P = ASORA_PHASE_CHUNKS, NW = THREADS / 64;
-    constexpr bool QUAD = QSHIFT != 0, OCT = QSHIFT == 3;
+    constexpr bool QUAD = QSHIFT != 0, OCT = QSHIFT == 3, PACK = SSHIFT != 0;
     static_assert(QSHIFT == 0 || QSHIFT == 2 || QSHIFT == 3, "1, 4 or 8 sectors per workgroup");
-    constexpr int QS = QSHIFT, NQ = 1 << QS, NS = QUAD ? 2 : 1;  // sectors per wave, sign sets per table
+    static_assert(SSHIFT == 0 || (QUAD && QSHIFT + SSHIFT <= 6), "source packing rides on the multi-sector kernels");
+    constexpr int QS = QSHIFT + SSHIFT;  // log2 of the lanes that share a cell
+    constexpr int NQ = 1 << QSHIFT, NSRC = 1 << SSHIFT, NS = QUAD ? 2 : 1;  // sectors, sources per wave; sign sets per table
     static_assert(!QUAD || LDS_STAGE, "the four-quadrant kernel stages in LDS");
     const double max_coldensh = (double)2e30f;  // raytracing.f90:368
     static_assert(LDS_STAGE || WSTAGED, "column-density-only staging is an LDS layout");
@@ -682,27 +692,36 @@ void sweep_tab_kernel(SweepArgs A) {
     const uint32_t N2 = (uint32_t)N * (uint32_t)N;
     // LDS (in doubles): [cw pairs: 2*E, or column densities: E rounded up to even (LDS staging only)] [du: 2W] [dv: 2W] [rowU, colV: W ints each] [log10 table]
     const int E = A.cw_entries, W = A.wtab;
-    const int SW = NS * W;  // entries per row / column table (QUAD: the +1 direction set, then the -1 set)
-    const int off_du = LDS_STAGE ? NQ * (WSTAGED ? 2 * E : (E + 1) & ~1) : 0;
+    const int SW1 = NS * W;     // entries per row / column table of ONE source (QUAD: the +1 direction set, then the -1 set)
+    const int SW = NSRC * SW1;  // ... of the workgroup's sources
+    const int off_du = LDS_STAGE ? NSRC * NQ * (WSTAGED ? 2 * E : (E + 1) & ~1) : 0;
     double2 *const du_tab = reinterpret_cast<double2 *>(asora_smem + off_du);
     double2 *const dv_tab = du_tab + SW;
     int *const rowU = reinterpret_cast<int *>(asora_smem + off_du + 4 * SW);
     int *const colV = rowU + SW;
     // the variant's plane table: read through LDS so that stepping to the next plane never touches vmcnt
     PlaneInfo *const planes = reinterpret_cast<PlaneInfo *>(asora_smem + off_du + 5 * SW + (SW & 1));
+    // PACK: the 1-based in-plane coordinates (u, v) of the group's sources, for the per-plane interpolation tables
+    int *const src_uv = reinterpret_cast<int *>(asora_smem + off_du + 5 * SW + (SW & 1) + PLANE_INFO_DOUBLES * A.nplanes);
+    const int off_log = off_du + 5 * SW + (SW & 1) + PLANE_INFO_DOUBLES * A.nplanes + (PACK ? NSRC : 0);
     C.stg.g = LDS_STAGE ? nullptr : reinterpret_cast<double2 *>(A.gscratch) + (size_t)blockIdx.x * (size_t)E;
-    C.lg = load_log10_table(A.log10_table, off_du + 5 * SW + (SW & 1) + PLANE_INFO_DOUBLES * A.nplanes, tid, THREADS);
-    // this lane's quadrant: staging array, sign sets
+    C.lg = load_log10_table(A.log10_table, off_log, tid, THREADS);
+    // this lane's quadrant and source of the group: staging array, sign sets
     const int quad = QUAD ? (lane & (NQ - 1)) : 0;
-    const uint32_t stg_q = (uint32_t)(quad * E);
-    const uint32_t set_u = QUAD ? (uint32_t)(((quad >> 1) & 1) * W) : 0u, set_v = QUAD ? (uint32_t)((quad & 1) * W) : 0u;
+    const int sgrp = PACK ? ((lane >> QSHIFT) & (NSRC - 1)) : 0;
+    const uint32_t stg_q = (uint32_t)((sgrp * NQ + quad) * E);
+    const uint32_t set_u = QUAD ? (uint32_t)(sgrp * SW1 + ((quad >> 1) & 1) * W) : 0u;
+    const uint32_t set_v = QUAD ? (uint32_t)(sgrp * SW1 + (quad & 1) * W) : 0u;
     const double w_empty = weightf(0.0, A.sig);  // weight of a guard / never-written entry
 
     for (long long task = blockIdx.x; task < A.ntasks; task += gridDim.x) {
         constexpr int TASKS_PER_SOURCE = SECTORS / NQ;
-        const int s = (int)(task / TASKS_PER_SOURCE);
+        const int s = (int)(task / TASKS_PER_SOURCE);  // source, or (PACK) group of NSRC consecutive sources
         const int t = (int)(task - (long long)s * TASKS_PER_SOURCE) * NQ;  // first sector of this task
-        const int src = A.src_begin + s;
+        const int src0 = A.src_begin + s * NSRC;       // first source of the group (wave-uniform)
+        // this lane's source; lanes of a partial last group re-read the last source and never produce output
+        const bool src_ok = !PACK || s * NSRC + sgrp < A.nsrc;
+        const int src = PACK ? min(src0 + sgrp, A.src_begin + A.nsrc - 1) : src0;
         const int axis = t >> 3;  // 0: z-dominant, 1: y-dominant, 2: x-dominant
         const int sp = OCT ? ((quad & 4) ? -1 : 1) : ((t & 4) ? -1 : 1);  // OCT: per lane
         const int su = QUAD ? ((quad & 2) ? -1 : 1) : ((t & 2) ? -1 : 1);  // QUAD: per lane
@@ -717,7 +736,10 @@ void sweep_tab_kernel(SweepArgs A) {
         const double *__restrict__ nhi = (axis == 0) ? A.nhiB : A.nhiA;
         double *__restrict__ phi = (axis == 0) ? A.phiB : A.phiA;
         double *__restrict__ heat = (axis == 0) ? A.heatB : A.heatA;
-        double *__restrict__ cdh = (src == A.cdh_src) ? ((axis == 0) ? A.cdhB : A.cdhA) : nullptr;
+        // column-density export: wave-uniform pointer when the group holds the exported source, per-lane flag
+        const bool cdh_group = PACK ? (A.cdh_src >= src0 && A.cdh_src < src0 + NSRC) : (src == A.cdh_src);
+        double *__restrict__ cdh = cdh_group ? ((axis == 0) ? A.cdhB : A.cdhA) : nullptr;
+        const bool cdh_lane = !PACK || src == A.cdh_src;
         const rsrc_t phi_rs = make_rsrc(phi, N2 * (uint32_t)N * 8u);
         const rsrc_t heat_rs = make_rsrc(HEAT ? heat : phi, N2 * (uint32_t)N * 8u);
         // ownership: reference tie order (z, y, x) and sign(0) = +1
@@ -725,7 +747,7 @@ void sweep_tab_kernel(SweepArgs A) {
                                    (axis == 2 ? FLAG_AN : 0u);
         // Cells outside the R-sphere (list B) are never upwind of a cell inside it: they only feed the exported
         // column density.  With "skip_unobserved" every other source sweeps list A only.
-        const bool rate_only = A.rate_only && src != A.cdh_src;
+        const bool rate_only = A.rate_only && !cdh_group;
         // (OCT: the host has checked q_max <= min(last_l, last_r): both pyramids march the same planes)
         const int nmax = min(min(OCT ? min(A.last_r, A.last_l) : (sp > 0 ? A.last_r : A.last_l), A.q_max),
                              rate_only ? A.nmax_rate : 0x7fffffff);
@@ -754,36 +776,61 @@ void sweep_tab_kernel(SweepArgs A) {
         // (the previous task's last barrier guarantees nobody still reads the arrays below)
         // entry i of a row / column table: offset i % W in direction +1 (first set) or, QUAD only, -1 (second set);
         // without QUAD the single set has the task's direction
-        auto table_dir = [&](int i, int s_task) { return QUAD ? (i >= W ? -1 : 1) : s_task; };
-        for (int i = tid; i < NQ * E; i += THREADS) C.stg.st((uint32_t)i, 0.0, w_empty);
+        // (entry i: source i / SW1 of the group, then as above within that source's SW1 entries)
+        auto table_dir = [&](int i, int s_task) { return QUAD ? ((PACK ? i % SW1 : i) >= W ? -1 : 1) : s_task; };
+        auto table_off = [&](int i) { const int j = PACK ? i % SW1 : i; return j >= W ? j - W : j; };
+        // in-plane source coordinates of table entry i's source: (wrapped u, wrapped v, 1-based u, 1-based v as given)
+        auto table_src = [&](int i, int &tu0, int &tv0, int &tur1, int &tvr1) {
+            if (!PACK) { tu0 = u0; tv0 = v0; tur1 = ur1; tvr1 = vr1; return; }
+            const int sj = min(src0 + i / SW1, A.src_begin + A.nsrc - 1);
+            const int ir = A.src_pos[3 * sj + 0], jr = A.src_pos[3 * sj + 1], kr = A.src_pos[3 * sj + 2];
+            const int ur = axis == 2 ? jr : ir, vr = axis == 0 ? jr : kr;
+            tu0 = fmodulo(ur, N); tv0 = fmodulo(vr, N); tur1 = ur + 1; tvr1 = vr + 1;
+        };
+        for (int i = tid; i < NSRC * NQ * E; i += THREADS) C.stg.st((uint32_t)i, 0.0, w_empty);
         for (int i = tid; i < SW; i += THREADS) {
-            const int o = i >= W ? i - W : i;
-            rowU[i] = (int)((uint32_t)wrap(u0 + table_dir(i, su) * o, N) * strideU);
-            colV[i] = wrap(v0 + table_dir(i, sv) * o, N);
+            int tu0, tv0, tur1, tvr1;
+            table_src(i, tu0, tv0, tur1, tvr1);
+            const int o = table_off(i);
+            rowU[i] = (int)((uint32_t)wrap(tu0 + table_dir(i, su) * o, N) * strideU);
+            colV[i] = wrap(tv0 + table_dir(i, sv) * o, N);
+            if (PACK && i % SW1 == 0) { src_uv[2 * (i / SW1)] = tur1; src_uv[2 * (i / SW1) + 1] = tvr1; }
         }
-        {
-            const double alam = planes[1].alam;
-            for (int i = tid; i < 2 * SW; i += THREADS) {
-                const int j = i < SW ? i : i - SW, o = j >= W ? j - W : j;
-                if (i < SW) du_tab[j] = interp_offsets(o, table_dir(j, su), ur1, alam);
-                else dv_tab[j] = interp_offsets(o, table_dir(j, sv), vr1, alam);
+        if (PACK) __syncthreads();  // src_uv
+        // interpolation offsets of plane n for every row / column of every source of the group
+        // ... of rows / columns 0 .. nlim only (plane n has none beyond min(n, W - 1)): entry i -> (table, sign set,
+        // source, offset) with the offsets padded to a power of two, so that small planes cost one short pass
+        auto fill_offsets = [&](double alam, int nlim) {
+            const int nl = min(nlim, W - 1);
+            const int sh = 32 - __clz(nl);  // 1 << sh > nl
+            constexpr int NSETS = NS * NSRC;
+            for (int i = tid; i < (2 * NSETS) << sh; i += THREADS) {
+                const int o = i & ((1 << sh) - 1), st = i >> sh;
+                if (o > nl) continue;
+                const bool is_u = st < NSETS;
+                const int s2 = is_u ? st : st - NSETS;        // (source, sign set) of this table
+                const int j = (s2 / NS) * SW1 + (s2 % NS) * W + o;
+                const int c1 = PACK ? src_uv[2 * (s2 / NS) + (is_u ? 0 : 1)] : (is_u ? ur1 : vr1);
+                if (is_u) du_tab[j] = interp_offsets(o, table_dir(j, su), c1, alam);
+                else dv_tab[j] = interp_offsets(o, table_dir(j, sv), c1, alam);
             }
-        }
+        };
+        fill_offsets(planes[1].alam, 1);
         __syncthreads();
-        if (tid < NQ) {
+        if (tid < NQ * NSRC) {
             // source cell, raytracing.f90:430-439 (QUAD: one copy per quadrant's staging array)
             const uint32_t g0 = (uint32_t)p0 * strideP + (uint32_t)u0 * strideU + (uint32_t)v0;
             double nHI = nhi[g0];
             double path = 0.5 * A.dr;
             double cdo = 0.0 + nHI * path;
             C.stg.st(pos00 + stg_q, cdo, weightf(cdo, A.sig));
-            if (t == 0 && tid == 0) {
+            if (t == 0 && quad == 0 && src_ok) {  // (tid < NQ * NSRC <= 64: tid is the lane number)
                 double vol_ph = A.dr * A.dr * A.dr;
                 double ph, ht = 0.0;
                 cell_rates<HEAT>(A, C.lg, flux, 0.0, cdo, vol_ph, nHI, ph, ht);
                 unsafeAtomicAdd(phi + g0, ph);
                 if (HEAT) unsafeAtomicAdd(heat + g0, ht);
-                if (cdh) cdh[g0] = cdo;
+                if (cdh && cdh_lane) cdh[g0] = cdo;
             }
         }
         __syncthreads();
@@ -854,9 +901,9 @@ void sweep_tab_kernel(SweepArgs A) {
                 wo[q] = WSTAGED ? weightf(c_out, A.sig) : 0.0;
                 woff[q] = valid ? (int)o_cur + 1 : -1;
                 const bool ghost = ((m.x >> META_FLAG_SHIFT) & ghostmask) != 0;
-                const bool own = valid && !ghost;
+                const bool own = valid && !ghost && src_ok;
                 if (with_cdh) {
-                    if (cdh && own) *ptr_byte(cdh, g_c[q] * 8u) = c_out;
+                    if (cdh && own && cdh_lane) *ptr_byte(cdh, g_c[q] * 8u) = c_out;
                 }
 #ifdef ASORA_ABL_NORATES
                 fire[q] = own && isA && cdh_in == 1.2345e300;  // ablation build: column densities only
@@ -875,7 +922,8 @@ void sweep_tab_kernel(SweepArgs A) {
             const bool all_rates = false;
 #else
             // (slot 0 holds the wave's highest chunk; with the heating tables the batch would spill)
-            const bool all_rates = !HEAT && all_on && d0.nchunk - 1 - (d0.jbase + wave) < d0.nchunkA;
+            // (... and so it does -- 20 to 37 registers -- in the packed kernels, whose lanes carry their own source)
+            const bool all_rates = !HEAT && !PACK && all_on && d0.nchunk - 1 - (d0.jbase + wave) < d0.nchunkA;
 #endif
             if (all_on) {
                 // the usual phase: every slot of this wave is occupied -> ONE basic block, so that the scheduler
@@ -956,14 +1004,8 @@ void sweep_tab_kernel(SweepArgs A) {
 #pragma unroll
             for (int q = 0; q < P; q++)
                 if (woff[q] >= 0) C.stg.st((uint32_t)woff[q], cdo[q], wo[q]);
-            if (d1.n != n) {  // last phase of this plane: interpolation offsets of the next one
-                const double alam_next = planes[min(n + 1, A.nplanes - 1)].alam;
-                for (int i = tid; i < 2 * SW; i += THREADS) {
-                    const int j = i < SW ? i : i - SW, o = j >= W ? j - W : j;
-                    if (i < SW) du_tab[j] = interp_offsets(o, table_dir(j, su), ur1, alam_next);
-                    else dv_tab[j] = interp_offsets(o, table_dir(j, sv), vr1, alam_next);
-                }
-            }
+            if (d1.n != n)  // last phase of this plane: interpolation offsets of the next one
+                fill_offsets(planes[min(n + 1, A.nplanes - 1)].alam, n + 1);
             phase_barrier<LDS_STAGE>();  // new values visible
             // ---- rotate the pipeline --------------------------------------------------------------
             d0 = d1;

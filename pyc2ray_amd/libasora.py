@@ -298,5 +298,6 @@ def last_sweep_ms():
 def last_launch_info():
     g, b, l, s = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     _check(_lib.asora_last_launch_info(C.byref(g), C.byref(b), C.byref(l), C.byref(s)))
-    return dict(grid=g.value, block=b.value, lds_bytes=l.value, staging={0: "global", 1: "lds", 2: "lds-compact"}[s.value & 3], quad=bool(s.value >> 2), sectors_per_workgroup=1 << (s.value >> 2),
+    return dict(grid=g.value, block=b.value, lds_bytes=l.value, staging={0: "global", 1: "lds", 2: "lds-compact"}[s.value & 3], quad=bool((s.value >> 2) & 3), sectors_per_workgroup=1 << ((s.value >> 2) & 3),
+                sources_per_workgroup=1 << ((s.value >> 4) & 3),
                 table_driven=bool(_lib.asora_last_sweep_is_table_driven()))

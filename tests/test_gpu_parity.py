@@ -348,6 +348,47 @@ def test_four_quadrant_kernel_equals_sector_kernel(asora, golden_dir, name, opts
     assert np.allclose(out_all[0], ref_all[0], rtol=1e-13, atol=0)
 
 
+@pytest.mark.parametrize("opts", [dict(quad_kernel=1, src_pack=2), dict(quad_kernel=1, src_pack=3),
+                                  dict(quad_kernel=2, src_pack=2), dict(quad_kernel=2, src_pack=3),
+                                  dict(quad_kernel=1, src_pack=2, skip_unobserved=1), dict(quad_kernel=2, src_pack=3, source_order=0)])
+@pytest.mark.parametrize("name", ["rcut7p3", "multi16_equal", "multi16_unequal", "same_cell_sources"])
+def test_source_packing_equals_sector_kernel(asora, golden_dir, name, opts):
+    """Several sources per workgroup (option src_pack: lane l on quadrant l & 3 / octant l & 7 of source (l >> 2 / 3) &
+    3 / 7 of its group; picked for the smallest radii) do the same arithmetic per cell and per source: single source and
+    every list length -- full groups, a partial last group -- give bit-identical column density and the same rate sum."""
+    c = load_golden(golden_dir, name)
+    heat = bool(c["heat_valid"])
+    ns_all = len(c["flux"])
+    asora.set_option("quad_kernel", -1)
+    try:
+        ref = {n: run_hip(asora, c, heat=heat, num_src=n) for n in sorted({1, min(5, ns_all), ns_all})}
+        assert not asora.last_launch_info()["quad"]
+    finally:
+        asora.set_option("quad_kernel", 0)
+    for k, v in opts.items():
+        asora.set_option(k, v)
+    try:
+        for n, r in ref.items():
+            out = run_hip(asora, c, heat=heat, num_src=n)
+            info = asora.last_launch_info()
+            assert info["sources_per_workgroup"] == 1 << opts["src_pack"] and info["block"] == 256, info
+            if name == "rcut7p3":
+                assert info["sectors_per_workgroup"] == (8 if opts["quad_kernel"] == 2 else 4), info
+            assert info["grid"] == (24 // info["sectors_per_workgroup"]) * -(-n // info["sources_per_workgroup"]), info
+            assert np.array_equal(out[1], r[1])                                   # column density of the last source
+            for a, b in ((out[0], r[0]), (out[2], r[2])):
+                if a is None:
+                    continue
+                assert np.array_equal(a != 0, b != 0)
+                if n == 1:
+                    assert np.array_equal(a, b)
+                else:
+                    assert np.allclose(a, b, rtol=1e-13, atol=0)
+    finally:
+        for k in opts:
+            asora.set_option(k, {"source_order": 2}.get(k, 0))
+
+
 @pytest.mark.parametrize("name", ["multi16_unequal", "rcut7p3", "lognormal48", "corner33"])
 def test_skip_unobserved_cells(asora, golden_dir, name):
     """Option skip_unobserved (off by default; never used by bench.py): cells outside the R-sphere are not
