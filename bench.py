@@ -163,8 +163,18 @@ def main():
     dev_index = local_rank % ngpu
     torch.cuda.set_device(dev_index)
     backend = None
-    if world > 1:
+    # ASORA_BENCH_FORCE_DIST=1: form the process group and run the collective even with ONE rank -- the only way to
+    # put the RCCL all-reduce and its stream ordering against the sweep under test on a single-GPU box
+    dist_on = world > 1 or os.environ.get("ASORA_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("ASORA_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -216,7 +226,7 @@ def main():
     def step():
         asora.do_all_sources_dev(a.R, 0, 6.30e-18, a.dr, xh_t.data_ptr(), phi_t.data_ptr(),
                                  heat_t.data_ptr() if a.heat else 0, ns_local, N, -20.0, inp["dlogtau"], num_tau, stream)
-        if world > 1:
+        if dist_on:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             if backend == "nccl":
@@ -235,7 +245,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -260,7 +270,7 @@ def main():
     k_ms = float(np.mean(kern_ms))
     ar_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ar_events])) if ar_events else 0.0
     per_rank = torch.tensor([dt, k_ms, ar_ms, 1.0, float(ns_local)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         gathered = [torch.empty_like(per_rank) for _ in range(world)]
         if backend != "nccl":
             gathered = [g.cpu() for g in gathered]
@@ -306,6 +316,9 @@ def main():
             hs.append(time.perf_counter() - th)
         host_api = {"ms_per_call": min(hs[1:]) * 1e3, "value": total_visits / min(hs[1:]),
                     "first_call_ms": hs[0] * 1e3,
+                    # the reference's own normalisation (docs/fig/scaling.jpg): wall time of this very call per source
+                    # and per cell of the R-sphere; published asymptotes at N = 200, R = 10: 1.466 ns (A100), 1.081 ns (GH200)
+                    "ns_per_source_per_sphere_cell": min(hs[1:]) / a.sources / (4.0 / 3.0 * np.pi * a.R ** 3) * 1e9,
                     "what": "asora_do_all_sources on host pointers: H2D xh_av + sweep + D2H phi_ion and coldensh_out"}
     asora.device_close()
     # second denominator: what a plain device-to-device copy achieves on this box
@@ -361,7 +374,7 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

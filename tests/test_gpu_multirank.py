@@ -48,3 +48,24 @@ def test_two_rank_bench_reproduces_single_rank_checksum():
     assert _last_json(ext.stdout)["ranks_seen"] == 2
     ca, cb = a["config"]["phi_checksum"], b["config"]["phi_checksum"]
     assert ca > 0 and abs(ca - cb) <= 1e-12 * ca, (ca, cb)  # sum order differs, nothing else
+
+
+@pytest.mark.gpu
+def test_rccl_allreduce_follows_the_sweep_on_its_stream():
+    """RCCL itself on the bench path (a one-GPU box cannot host two RCCL ranks): ASORA_BENCH_FORCE_DIST=1 forms a
+    one-rank "nccl" process group, so every step runs sweep -> dist.all_reduce(phi_ion) through RCCL on torch's
+    current stream -- the stream the library launched the sweep on.  A missing ordering between the two would
+    reduce a half-written grid: the checksum must equal the plain run's, over several steps."""
+    args = ["--N", "64", "--sources", "481", "--R", "20", "--no-cpu", "--no-host-api", "--steps", "4", "--warmup", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                           timeout=300, cwd=ROOT, env=env)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    rccl = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                          timeout=300, cwd=ROOT, env=dict(env, ASORA_BENCH_FORCE_DIST="1"))
+    assert rccl.returncode == 0, rccl.stderr[-2000:]
+    a, b = _last_json(plain.stdout), _last_json(rccl.stdout)
+    assert a["backend"] is None and b["backend"] == "nccl" and b["ranks_seen"] == 1 and b["n_gpus"] == 1
+    assert b["per_rank"]["allreduce_ms"][0] > 0.0
+    ca, cb = a["config"]["phi_checksum"], b["config"]["phi_checksum"]
+    assert ca > 0 and abs(ca - cb) <= 1e-12 * ca, (ca, cb)
