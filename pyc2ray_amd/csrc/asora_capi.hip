@@ -98,6 +98,7 @@ struct State {
     int last_pack = 0;
     int compact_staging = 0;      // option "compact_staging": stage column densities only (0: automatic, 1: always, -1: never)
     int skip_unobserved = 0;      // option "skip_unobserved": cells outside the R-sphere only for the exported column density
+    int skip_saturated = 0;       // option "skip_saturated": no rate evaluation behind optical depths beyond the table's end
     int force_generic = 0;        // option "force_generic": always use the table-free kernel
     long long max_table_cells = 48LL << 20;  // option "max_table_cells": beyond this the generic kernel runs
     int last_tab = 0;
@@ -344,12 +345,12 @@ int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
     return 0;
 }
 
-template <bool L, bool H, int T, bool WS = true, int QD = 0, int SS = 0>
+template <bool L, bool H, int T, bool WS = true, int QD = 0, int SS = 0, bool SAT = false>
 int launch_sweep_tab(const asora::SweepArgs &A, int grid, size_t lds, hipStream_t st) {
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)asora::sweep_tab_kernel<L, H, T, WS, QD, SS>,
+        HIP_TRY(hipFuncSetAttribute((const void *)asora::sweep_tab_kernel<L, H, T, WS, QD, SS, SAT>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((asora::sweep_tab_kernel<L, H, T, WS, QD, SS>), dim3(grid), dim3(T), lds, st, A);
+    hipLaunchKernelGGL((asora::sweep_tab_kernel<L, H, T, WS, QD, SS, SAT>), dim3(grid), dim3(T), lds, st, A);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -499,6 +500,10 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     A.num_tau = num_tau;
     A.R = R; A.sig = sig; A.dr = dr; A.minlogtau = minlogtau; A.dlogtau = dlogtau;
     A.rdlogtau = 1.0 / dlogtau;
+    // "skip_saturated": from tau_sat on, 1 + (log10(tau) - minlogtau) / dlogtau >= num_tau, i.e. photo_lookuptable clamps to
+    // the last entry (photorates.f90:140-146).  The margin of 1e-6 table steps is ~1e9 times the error of the device's
+    // log10 and division, so a lane that passes the test clamps for certain.
+    A.tau_sat = std::pow(10.0, minlogtau + ((double)num_tau - 1.0 + 1.0e-6) * dlogtau) * (1.0 + 1.0e-12);
     // widest plane any sector stages: max_n min(n, lim, q_max - n) + 1, lim = max(last_l, last_r)
     const int wmax = plane_extent(A.q_max, A.last_l, A.last_r);
     A.S = wmax + 2;  // b = -1 guard .. wmax
@@ -658,8 +663,16 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         HIP_TRY(hipEventRecord(S.ev0, st));
         if (use_tab) {
             constexpr int T = asora::SWEEP_THREADS;
+            // ("skip_saturated": the LDS-staged single-sector kernels of 256 / 512 / 1024 threads have a variant with the test
+            // compiled in -- the radii at which a source's light can saturate the table; the others ignore the option)
+            const bool sat = S.skip_saturated && !quad && use_lds && threads >= 256;
 #define ASORA_LAUNCH_TAB(L, TH, WS) \
+    (sat && L && TH >= 256 ? ASORA_LAUNCH_SAT(TH, WS) : ASORA_LAUNCH_PLAIN(L, TH, WS))
+#define ASORA_LAUNCH_PLAIN(L, TH, WS) \
     (want_heat ? launch_sweep_tab<L, true, TH, WS>(A, grid, lds, st) : launch_sweep_tab<L, false, TH, WS>(A, grid, lds, st))
+#define ASORA_LAUNCH_SAT(TH, WS) \
+    (want_heat ? launch_sweep_tab<true, true, (TH >= 256 ? TH : 256), WS, 0, 0, true>(A, grid, lds, st) \
+               : launch_sweep_tab<true, false, (TH >= 256 ? TH : 256), WS, 0, 0, true>(A, grid, lds, st))
 #define ASORA_LAUNCH_QUAD(TH, WS, QD) \
     (want_heat ? launch_sweep_tab<true, true, TH, WS, QD>(A, grid, lds, st) \
                : launch_sweep_tab<true, false, TH, WS, QD>(A, grid, lds, st))
@@ -692,6 +705,8 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             else if (use_lds) rc = ASORA_LAUNCH_TAB(true, T, true);
             else rc = ASORA_LAUNCH_TAB(false, T, true);
 #undef ASORA_LAUNCH_TAB
+#undef ASORA_LAUNCH_PLAIN
+#undef ASORA_LAUNCH_SAT
 #undef ASORA_LAUNCH_QUAD
 #undef ASORA_LAUNCH_QUAD_T
 #undef ASORA_LAUNCH_PACK
@@ -825,7 +840,7 @@ int asora_device_close(void) {
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     State fresh;  // options and the last launch record survive a close
-    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.compact_staging = S.compact_staging; fresh.quad_kernel = S.quad_kernel; fresh.quad_max_entries = S.quad_max_entries; fresh.oct_max_entries = S.oct_max_entries; fresh.last_quad = S.last_quad; fresh.src_pack = S.src_pack; fresh.pack_max_lds = S.pack_max_lds; fresh.pack_max_entries = S.pack_max_entries; fresh.max_table_cells = S.max_table_cells;
+    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.skip_saturated = S.skip_saturated; fresh.compact_staging = S.compact_staging; fresh.quad_kernel = S.quad_kernel; fresh.quad_max_entries = S.quad_max_entries; fresh.oct_max_entries = S.oct_max_entries; fresh.last_quad = S.last_quad; fresh.src_pack = S.src_pack; fresh.pack_max_lds = S.pack_max_lds; fresh.pack_max_entries = S.pack_max_entries; fresh.max_table_cells = S.max_table_cells;
     fresh.last_tab = S.last_tab; fresh.last_grid = S.last_grid; fresh.last_block = S.last_block;
     fresh.last_lds = S.last_lds; fresh.last_is_lds = S.last_is_lds;
     const int dev = S.device;
@@ -1140,6 +1155,7 @@ int asora_set_option(const char *name, long long value) {
     else if (!std::strcmp(name, "pack_max_lds")) S.pack_max_lds = (int)value;
     else if (!std::strcmp(name, "pack_max_entries")) S.pack_max_entries = (int)value;
     else if (!std::strcmp(name, "skip_unobserved")) S.skip_unobserved = value != 0;
+    else if (!std::strcmp(name, "skip_saturated")) S.skip_saturated = value != 0;
     else return fail(12, "asora_set_option: unknown option '%s'", name);
     return 0;
 }

@@ -95,6 +95,7 @@ struct SweepArgs {
     int vmap[8];               // ((u_is_neg*2 + v_is_neg)*2 + (axis != 0)) -> variant
     int rate_only;             // option "skip_unobserved": sources other than cdh_src sweep list A only
     int nmax_rate;             // last plane with a cell inside the R-sphere
+    double tau_sat;            // optical depth from which both table look-ups of a cell clamp to the last entry
 };
 
 // ------------------------------------------------------------------------------------------
@@ -672,9 +673,11 @@ __device__ __forceinline__ void phase_barrier() {
 // R = 5 a plane of one source fills half a wavefront, eight sources fill it, and the per-task set-up (tables, plane
 // list, log10 table, first loads) is paid once per group.  Per (source, quadrant): staging array; per source: row /
 // column / interpolation tables (the interpolation carries the source's own coordinate), flux, position.
-template <bool LDS_STAGE, bool HEAT, int THREADS, bool WSTAGED, int QSHIFT = 0, int SSHIFT = 0>
+// SATSKIP: option "skip_saturated" compiled in (single-sector kernels only; a run-time test costs the default path 2 %).
+template <bool LDS_STAGE, bool HEAT, int THREADS, bool WSTAGED, int QSHIFT = 0, int SSHIFT = 0, bool SATSKIP = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(ASORA_WAVES_PER_EU, ASORA_WAVES_PER_EU)))
 void sweep_tab_kernel(SweepArgs A) {
+    static_assert(!SATSKIP || QSHIFT == 0, "skip_saturated rides on the single-sector kernels");
     constexpr int P = ASORA_PHASE_CHUNKS, NW = THREADS / 64;
     constexpr bool QUAD = QSHIFT != 0, OCT = QSHIFT == 3, PACK = SSHIFT != 0;
     static_assert(QSHIFT == 0 || QSHIFT == 2 || QSHIFT == 3, "1, 4 or 8 sectors per workgroup");
@@ -923,7 +926,9 @@ void sweep_tab_kernel(SweepArgs A) {
 #else
             // (slot 0 holds the wave's highest chunk; with the heating tables the batch would spill)
             // (... and so it does -- 20 to 37 registers -- in the packed kernels, whose lanes carry their own source)
-            const bool all_rates = !HEAT && !PACK && all_on && d0.nchunk - 1 - (d0.jbase + wave) < d0.nchunkA;
+            // ... and in the single-wave multi-sector kernels (R <~ 12), where batching costs 2 - 8 %)
+            const bool all_rates = !HEAT && !PACK && !(QUAD && THREADS == 64) && all_on &&
+                                   d0.nchunk - 1 - (d0.jbase + wave) < d0.nchunkA;
 #endif
             if (all_on) {
                 // the usual phase: every slot of this wave is occupied -> ONE basic block, so that the scheduler
@@ -959,10 +964,33 @@ void sweep_tab_kernel(SweepArgs A) {
                     nhi_n[q] = at_byte(nhi, g_n[q] * 8u);
                 }
             }
+            // Option "skip_saturated".  Behind an optical depth beyond the table's last entry both look-ups of a thick cell
+            // clamp to that entry with residual 0, so phi_in == phi_out bit for bit and the cell's rate (and heating
+            // rate) is exactly +0: adding it changes nothing.  Such lanes stop firing, and a slot none of whose lanes
+            // fires skips its rates altogether (photorates.f90:113-125, 139-146: same values, no work).
+            bool slot_live[P];
+            // (Not in the multi-sector kernels of the small radii: their registers are spoken for, and a source's
+            // light rarely saturates within ~45 cells.)
+            if (SATSKIP) {
+                const double tau_photo_limit = (double)1.0e-7f;
+#pragma unroll
+                for (int q = 0; q < P; q++) {
+                    const double tau_in = cin[q] * A.sig, tau_out = cdo[q] * A.sig;
+                    const bool sat = tau_in >= A.tau_sat && fabs(tau_out - tau_in) > tau_photo_limit;
+                    fire[q] = fire[q] && !sat;
+                    slot_live[q] = __builtin_amdgcn_ballot_w64(fire[q]) != 0;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < P; q++) slot_live[q] = true;
+            }
+            bool all_live = true;
+#pragma unroll
+            for (int q = 0; q < P; q++) all_live = all_live && slot_live[q];
             __builtin_amdgcn_s_setprio(2);
             // rates: when every slot of the wave holds rate-producing cells, all of them together (their log10 /
             // look-up chains interleave); otherwise one slot at a time
-            if (all_rates) {
+            if (all_rates && all_live) {
                 RatePrep rp[P];
                 RateLoads rl[P];
 #pragma unroll
@@ -979,7 +1007,7 @@ void sweep_tab_kernel(SweepArgs A) {
             } else {
 #pragma unroll
                 for (int q = 0; q < P; q++)
-                    if (rate_slot[q]) {
+                    if (rate_slot[q] && slot_live[q]) {
                         const RatePrep rp = rates_prepare(A, C.lg, flux, cin[q], cdo[q], geo_c[q].y);
                         const RateLoads rl = rates_load<HEAT>(A, rp);
                         double p_, h_ = 0.0;

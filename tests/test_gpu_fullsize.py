@@ -141,6 +141,22 @@ def test_flux_linearity_and_translation_256(asora):
     assert np.array_equal(phi3 != 0, m) and np.max(np.abs(phi3[m] / ref[m] - 1.0)) <= 1e-8
 
 
+def test_skip_saturated_on_the_bench_config(asora):
+    """The headline workload is optically thick (tau ~ 290 per cell; the table ends at tau = 1e4): with skip_saturated
+    the cells beyond ~35 cells of a source evaluate no rates.  Bit-identical single-source grid, same sum for a list."""
+    c = bench_case(24)
+    ref1, ref = run_hip(asora, c, num_src=1), run_hip(asora, c)
+    asora.set_option("skip_saturated", 1)
+    try:
+        out1, out = run_hip(asora, c, num_src=1), run_hip(asora, c)
+    finally:
+        asora.set_option("skip_saturated", 0)
+    assert np.array_equal(out1[0], ref1[0]) and np.array_equal(out1[1], ref1[1]) and np.array_equal(out[1], ref[1])
+    assert np.array_equal(out[0] != 0, ref[0] != 0) and np.allclose(out[0], ref[0], rtol=1e-13, atol=0)
+    inside = asora.geometry_census(c["R"], c["dr"], c["N"])["owned_rate"]
+    assert (ref1[0] != 0).sum() < 0.3 * inside   # most of the R-sphere is behind the table's end here
+
+
 def test_config0_single_source_128_vs_oracle(asora, port_oracle, ref_oracle):
     """BASELINE configs[0] (examples/unit_tests_hackathon/1_single_black_body): one 1e49 s^-1 source at
     1-based (96, 96, 64) in a uniform 128^3 box, black body 5e4 K, R_max = 150 cells (full box)."""

@@ -24,10 +24,11 @@ VARIANTS = [dict(), dict(wg_threads=64), dict(wg_threads=128), dict(wg_threads=1
             dict(quad_kernel=1, skip_unobserved=1), dict(quad_kernel=2), dict(quad_kernel=2, wg_threads=128),
             dict(quad_kernel=2, compact_staging=1, skip_unobserved=1),
             dict(quad_kernel=1, src_pack=2), dict(quad_kernel=1, src_pack=3), dict(quad_kernel=2, src_pack=2),
-            dict(quad_kernel=2, src_pack=3, skip_unobserved=1)]
+            dict(quad_kernel=2, src_pack=3, skip_unobserved=1), dict(skip_saturated=1, quad_kernel=-1),
+            dict(skip_saturated=1, quad_kernel=-1, wg_threads=512, compact_staging=1)]
 
 
-@pytest.mark.parametrize("seed", range(144))
+@pytest.mark.parametrize("seed", range(156))
 def test_random_small_case_vs_oracle(asora, port_oracle, seed):
     rng = np.random.default_rng(9000 + seed)
     N = MESHES[seed % len(MESHES)]

@@ -406,6 +406,34 @@ def test_skip_unobserved_cells(asora, golden_dir, name):
     assert np.allclose(phi1, phi0, rtol=1e-13, atol=0)
 
 
+@pytest.mark.parametrize("opts", [dict(quad_kernel=-1), dict(quad_kernel=-1, wg_threads=64), dict(quad_kernel=-1, wg_threads=1024, compact_staging=1),
+                                  dict(quad_kernel=-1, skip_unobserved=1), dict(lds_stage_limit=1024), dict()])
+@pytest.mark.parametrize("name", ["thick24", "capped16", "shadow32", "lognormal48", "multi16_unequal"])
+def test_skip_saturated_cells(asora, golden_dir, name, opts):
+    """Option skip_saturated (off by default; never used by bench.py): behind an optical depth beyond the table's last
+    entry both look-ups of a thick cell clamp to that entry (photorates.f90:140-146), its rate is exactly +0, and the
+    kernel skips the evaluation.  Same numbers: single source bit-identical (phi, heat, coldensh_out), all sources the
+    same sum and support; thick24 (tau ~ 290 per cell) is saturated from the 35th cell on."""
+    c = load_golden(golden_dir, name)
+    heat = bool(c["heat_valid"])
+    for k, v in opts.items():
+        asora.set_option(k, v)
+    try:
+        ref1, ref = run_hip(asora, c, heat=heat, num_src=1), run_hip(asora, c, heat=heat)
+        asora.set_option("skip_saturated", 1)
+        out1, out = run_hip(asora, c, heat=heat, num_src=1), run_hip(asora, c, heat=heat)
+    finally:
+        asora.set_option("skip_saturated", 0)
+        for k in opts:
+            asora.set_option(k, 0)
+    for a, b in zip(out1, ref1):
+        assert (a is None and b is None) or np.array_equal(a, b)
+    assert np.array_equal(out[1], ref[1])
+    for a, b in ((out[0], ref[0]), (out[2], ref[2])):
+        if a is not None:
+            assert np.array_equal(a != 0, b != 0) and np.allclose(a, b, rtol=1e-13, atol=0)
+
+
 def test_error_reporting(asora):
     """Errors surface as RuntimeError instead of being swallowed."""
     with pytest.raises(RuntimeError):
