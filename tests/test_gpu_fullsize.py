@@ -157,6 +157,27 @@ def test_skip_saturated_on_the_bench_config(asora):
     assert (ref1[0] != 0).sum() < 0.3 * inside   # most of the R-sphere is behind the table's end here
 
 
+def test_staged_host_copies_equal_plain_copies(asora):
+    """The host-pointer entry points move their N^3 grids with `copy_threads` host threads staging 8 MiB chunks through
+    page-locked slots (grids of at least 32 MiB; option copy_threads, 0 = one plain hipMemcpy per grid): same bytes
+    either way -- input (a non-uniform xh_av must arrive intact) and all three outputs, odd sizes included."""
+    N = 177  # 5 545 233 cells = 44.4 MB per grid: five full chunks and a ragged sixth
+    rng = np.random.default_rng(2)
+    c = cases._base(N, 30.0, 3.0 * MPC / 200, [[5, 170, 88]], [3.0], ndens=cases.lognormal_density(N, 3, smooth=2.0),
+                    xh=rng.uniform(1e-4, 0.5, (N, N, N)), table_kw=dict(temp=1e5, numtau=20000))
+    out = {}
+    for threads in (0, 1, 4, 7):
+        asora.set_option("copy_threads", threads)
+        try:
+            out[threads] = run_hip(asora, c, heat=True)
+        finally:
+            asora.set_option("copy_threads", 4)
+    for threads in (1, 4, 7):
+        for a, b in zip(out[threads], out[0]):
+            assert np.array_equal(a, b)
+    assert (out[0][0] > 0).sum() > 50_000 and (out[0][2] > 0).sum() > 50_000
+
+
 def test_config0_single_source_128_vs_oracle(asora, port_oracle, ref_oracle):
     """BASELINE configs[0] (examples/unit_tests_hackathon/1_single_black_body): one 1e49 s^-1 source at
     1-based (96, 96, 64) in a uniform 128^3 box, black body 5e4 K, R_max = 150 cells (full box)."""
