@@ -1034,7 +1034,14 @@ void sweep_tab_kernel(SweepArgs A) {
                 if (woff[q] >= 0) C.stg.st((uint32_t)woff[q], cdo[q], wo[q]);
             if (d1.n != n)  // last phase of this plane: interpolation offsets of the next one
                 fill_offsets(planes[min(n + 1, A.nplanes - 1)].alam, n + 1);
-            phase_barrier<LDS_STAGE>();  // new values visible
+            // New values visible -- to the NEXT PLANE.  Within a plane the next phase takes lower chunks of the sequence:
+            // it reads old values at positions below everything this phase writes (A cells read A cells only; inside a
+            // list positions fall with the sequence) and writes only behind its own barrier, so with the staging in LDS
+            // (one program order per wave) no second barrier is needed between the phases of a plane.
+#ifndef ASORA_TWO_BARRIERS
+            if (!LDS_STAGE || d1.n != n)
+#endif
+            phase_barrier<LDS_STAGE>();
             // ---- rotate the pipeline --------------------------------------------------------------
             d0 = d1;
             d1 = phase_next<NW * P, QS>(d1, planes, nmax, rate_only);
