@@ -562,8 +562,9 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         if (quad && S.src_pack >= 0 && S.compact_staging <= 0 && (S.wg_threads == 0 || S.wg_threads == 256)) {
             // (measured, 1e4 sources at 256^3, unpacked -> four sources per workgroup: R = 3 0.21 -> 0.13 ms, R = 5 0.30 -> 0.27,
             // R = 8 0.76 -> 0.66; R = 10 1.08 -> 1.17: from there on a phase of one source keeps the wavefronts busy and
-            // the packed lanes' rate atomics meet in the same cells; eight sources never beat four)
-            for (int ss = (S.src_pack > 0 ? S.src_pack : 2); ss >= 2; ss--) {
+            // the packed lanes' rate atomics meet in the same cells)
+            // eight sources per workgroup pay up to ~32 staged entries (R <= 5: 1e5 sources 2.12 -> 1.87 ms, R = 3 0.175 -> 0.133)
+            for (int ss = (S.src_pack > 0 ? S.src_pack : (A.cw_entries <= 32 ? 3 : 2)); ss >= 2; ss--) {
                 if (qshift + ss > 6) continue;
                 lds_need(qshift, ss, true);
                 const size_t full = lds_stage + lds_fixed + (size_t)S.lds_pad;
@@ -1131,14 +1132,16 @@ int asora_global_pass(double dt, const double *ndens, const double *temp, const 
     for (double *&b : S.chem_buf)
         if (int rc = alloc_grid(b)) return rc;
     const double *src[7] = {ndens, temp, xh, xh_av, xh_intermed, phi_ion, clump};
-    for (int i = 0; i < 7; i++) HIP_TRY(hipMemcpy(S.chem_buf[i], src[i], bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());  // (the staged copies run on streams of their own)
+    for (int i = 0; i < 7; i++)
+        if (int rc = staged_copy(S.chem_buf[i], const_cast<double *>(src[i]), bytes, true)) return rc;
     long long cf = 0;
     if (int rc = asora_global_pass_dev(dt, S.chem_buf[0], S.chem_buf[1], S.chem_buf[2], S.chem_buf[3], S.chem_buf[4],
                                        S.chem_buf[5], S.chem_buf[6], bh00, albpow, colh0, temph0, abu_c, m1, &cf,
                                        nullptr, nullptr, nullptr))
         return rc;
-    HIP_TRY(hipMemcpy(xh_av, S.chem_buf[3], bytes, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(xh_intermed, S.chem_buf[4], bytes, hipMemcpyDeviceToHost));
+    if (int rc = staged_copy(S.chem_buf[3], xh_av, bytes, false)) return rc;  // (asora_global_pass_dev has waited for the stream)
+    if (int rc = staged_copy(S.chem_buf[4], xh_intermed, bytes, false)) return rc;
     *conv_flag = (int)cf;
     return 0;
 }
