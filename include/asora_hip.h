@@ -187,7 +187,12 @@ int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_i
  * "source_order" (see asora_source_order),
  * "skip_unobserved" (1: cells outside the R-sphere -- never upwind of a cell inside it -- are swept only for
  * the source whose column density is exported; phi and coldensh_out unchanged, ~27 % less time at 256^3 / R = 60;
- * off by default so that the default path visits exactly the cells the reference visits), "lds_pad" (extra LDS per workgroup, occupancy experiments). */
+ * off by default so that the default path visits exactly the cells the reference visits),
+ * "skip_saturated" (1: cells behind an optical depth beyond the photo table's last entry -- where both look-ups of
+ * photo_lookuptable clamp to that entry and the rate is exactly +0, photorates.f90:140-146 -- evaluate no rates;
+ * identical results; LDS-staged single-sector kernels of >= 256 threads only; off by default),
+ * "copy_threads" (host threads staging the grids of the host-pointer entry points through page-locked memory,
+ * default 4, 0: plain hipMemcpy), "lds_pad" (extra LDS per workgroup, occupancy experiments). */
 int asora_set_option(const char *name, long long value);
 
 /* 1 if the last sweep ran the table-driven kernel, 0 for the table-free one. */

@@ -123,7 +123,8 @@ def test_tiny_radius_vs_oracle(asora, port_oracle, R):
     assert (phi != 0).sum() >= 2
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(quad_kernel=-1), dict(force_generic=1), dict(source_order=0)])
+@pytest.mark.parametrize("opts", [dict(), dict(quad_kernel=-1), dict(force_generic=1), dict(source_order=0),
+                                  dict(R=4.0, quad_kernel=1, src_pack=2), dict(R=4.0, quad_kernel=2, src_pack=3)])
 def test_source_positions_are_periodic(asora, port_oracle, ref_oracle, opts):
     """The reference is built with -DPERIODIC (src/asora/meson.build:33): source coordinates outside [0, N) -- the
     1-based lists of read_sources / generate_test_sourcefile contain N -- address cell (coordinate mod N), while the
@@ -131,12 +132,16 @@ def test_source_positions_are_periodic(asora, port_oracle, ref_oracle, opts):
     the usual bar for the rates, bit-identical column density (which a wrap on upload would not give: the
     rounding of alam*di + real(i0) depends on i0)."""
     N = 24
-    c = cases._base(N, 9.0, 5e20, [[N, -1, 5], [3, N + 2, -N - 3], [2 * N, 7, 7]], [1.0, 2.0, 0.5],
+    opts = dict(opts)
+    R = opts.pop("R", 9.0)  # (R = 4: the multi-sector kernels with several sources per workgroup apply)
+    c = cases._base(N, R, 5e20, [[N, -1, 5], [3, N + 2, -N - 3], [2 * N, 7, 7]], [1.0, 2.0, 0.5],
                     ndens=cases.lognormal_density(N, 4))
     for k, v in opts.items():
         asora.set_option(k, v)
     try:
         phi, cdh, _ = run_hip(asora, c)
+        if "src_pack" in opts:
+            assert asora.last_launch_info()["sources_per_workgroup"] == 1 << opts["src_pack"]
     finally:
         for k in opts:
             asora.set_option(k, {"source_order": 2}.get(k, 0))
