@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times the chemistry pass (asora_global_pass_dev) on device-resident 256^3 grids.
+"""Times the chemistry pass (asora_global_pass_dev) on device-resident 256^3 grids: chem_bench.py [N] [isothermal].
 Algorithmic bytes: 5 streams read + 2 read-modify-written = 72 B per cell."""
 import json
 import os
@@ -16,6 +16,8 @@ from pyc2ray_amd import libasora as asora  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 c = cases.chemistry_case(N=N, seed=1)
+if len(sys.argv) > 2 and sys.argv[2] == "isothermal":  # what every driver of the reference passes: temp0 * ones
+    c["temp"] = np.full_like(c["temp"], 1.0e4)
 keys = ("ndens", "temp", "xh", "xh_av", "xh_intermed", "phi_ion", "clump")
 dev = torch.device("cuda", 0)
 t0 = {k: torch.from_numpy(c[k].ravel().copy()).to(dev) for k in keys}
@@ -37,4 +39,4 @@ for label, dt in (("hard (random cells, many inner iterations)", c["dt"]), ("eas
     best = float(np.median(ms[1:]))
     res[label] = dict(ms=best, GBps=72.0 * N ** 3 / best / 1e6, frac_of_8TBps=72.0 * N ** 3 / best / 1e6 / 8000.0)
 asora.device_close()
-print(json.dumps(dict(N=N, results=res)))
+print(json.dumps(dict(N=N, temperature=sys.argv[2] if len(sys.argv) > 2 else "random 1e2..1e5 K", results=res)))

@@ -15,7 +15,10 @@
 // sum(1 - xh_intermed) with two more passes over the grid on the host (evolve.py:350-351); here the
 // three reductions (conv_flag and the two sums) ride along: DPP-free wave shuffles, one LDS stage,
 // three atomics per workgroup.  The temperature-only factors (recombination and collisional
-// coefficients, one pow + one exp + one sqrt) are hoisted out of the fixed-point loop.
+// coefficients, one pow + one exp + one sqrt) are hoisted out of the fixed-point loop, and kept from
+// cell to cell while the temperature does not change (the reference's drivers pass temp0 * ones):
+// 256^3, one inner iteration per cell: 0.233 ms = 5.2 TB/s of the 72 B/cell (the device's copy rate);
+// with a different temperature in every cell 0.38 ms (470 VALU instructions per cell, VALU 67 % busy).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -53,16 +56,39 @@ __global__ __launch_bounds__(CHEM_THREADS) void chemistry_kernel(ChemArgs A) {
     unsigned long long nconv = 0;
     double s1 = 0.0, s0 = 0.0;
     const long long stride = (long long)gridDim.x * CHEM_THREADS;
-    for (long long id = (long long)blockIdx.x * CHEM_THREADS + threadIdx.x; id < A.ncell; id += stride) {
-        const double ndens_p = A.ndens[id], temp_p = A.temp[id], xh_p = A.xh[id];
-        const double phi_p = A.phi_ion[id], clump_p = A.clump[id];
-        const double xh_av_in = A.xh_av[id];
-        double xh_av_p = xh_av_in, xh_intermed_p = A.xh_intermed[id];
+    // The input streams of the NEXT cell of this lane are requested before the current cell's arithmetic runs
+    // (xh_intermed is write-only: the fixed point always assigns it before it is read).
+    struct CellIn { double ndens, temp, xh, phi, clump, xh_av; };
+    auto fetch = [&](long long i) {
+        CellIn c;
+        c.ndens = __builtin_nontemporal_load(A.ndens + i); c.temp = __builtin_nontemporal_load(A.temp + i);
+        c.xh = __builtin_nontemporal_load(A.xh + i); c.phi = __builtin_nontemporal_load(A.phi_ion + i);
+        c.clump = __builtin_nontemporal_load(A.clump + i); c.xh_av = A.xh_av[i];
+        return c;
+    };
+    double temp_key = __builtin_nan(""), pow_t4 = 0.0, acolh0 = 0.0;  // (NaN never compares equal: first cell computes)
+    long long id = (long long)blockIdx.x * CHEM_THREADS + threadIdx.x;
+    CellIn nxt = fetch(id < A.ncell ? id : 0);
+    for (; id < A.ncell; id += stride) {
+        const CellIn cur = nxt;
+        nxt = fetch(id + stride < A.ncell ? id + stride : id);
+        const double ndens_p = cur.ndens, temp_p = cur.temp, xh_p = cur.xh;
+        const double phi_p = cur.phi, clump_p = cur.clump;
+        const double xh_av_in = cur.xh_av;
+        double xh_av_p = xh_av_in, xh_intermed_p;
         const double yh_av_p = 1.0 - xh_av_p;                   // chemistry.f90:98
-        // doric, temperature-only part (chemistry.f90:261-266); isothermal => loop invariant
-        const double brech0 = clump_p * A.bh00 * pow(temp_p / t4, A.albpow);
-        const double sqrtt0 = sqrt(temp_p);
-        const double acolh0 = A.colh0 * sqrtt0 * exp(-A.temph0 / temp_p);
+        // doric, temperature-only part (chemistry.f90:261-266); isothermal => invariant of the fixed-point loop
+        // Every driver of the reference fills the temperature grid with ONE value (temp0 * ones, c2ray_test.py:175,
+        // c2ray_cubep3m.py:239): the two temperature-only factors -- 300 of the 470 instructions of a cell -- are
+        // kept while no lane of the wavefront sees its temperature change (same function of the same argument:
+        // bit-identical).
+        if (__builtin_amdgcn_ballot_w64(temp_p != temp_key) != 0) {
+            temp_key = temp_p;
+            pow_t4 = pow(temp_p / t4, A.albpow);
+            const double sqrtt0 = sqrt(temp_p);
+            acolh0 = A.colh0 * sqrtt0 * exp(-A.temph0 / temp_p);
+        }
+        const double brech0 = clump_p * A.bh00 * pow_t4;
         int nit = 0;
         for (;;) {                                              // do_chemistry, chemistry.f90:151-208
             nit = nit + 1;

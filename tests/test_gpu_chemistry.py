@@ -66,6 +66,54 @@ def test_global_pass_dev_stats(asora, port_oracle):
     assert abs(s0 - (1.0 - xi).sum()) <= 1e-9 * (1.0 - xi).sum()
 
 
+@pytest.mark.parametrize("temperature", ["uniform", "slabs", "striped"])
+def test_temperature_factors_kept_from_cell_to_cell(asora, port_oracle, temperature):
+    """The kernel keeps the temperature-only factors of a lane while its temperature repeats (asora_chem.hpp).
+    112^3 cells on at most 2^20 lanes: the cells from 2^20 on are some lanes' SECOND cells.  The same cells run as
+    64^3 sub-problems (one cell per lane, nothing kept) must give the same bits; and the whole pass meets the oracle.
+    uniform: what the reference's drivers pass (temp0 * ones); slabs: the value changes at a few places, inside
+    wavefronts too; striped: period 3 cells, so a lane's two cells never agree."""
+    import torch
+    N, M = 112, 64
+    c = cases.chemistry_case(N=N, seed=23)
+    n = N ** 3
+    assert n > 2 ** 20 + M ** 3
+    flat = np.empty(n)
+    if temperature == "uniform":
+        flat[:] = 1.0e4
+    elif temperature == "slabs":
+        edges = [0, 1000, 300001, 2 ** 20 + 17, 2 ** 20 + 5000, 1300003, n]
+        for v, (a, b) in zip([8.0e3, 1.0e4, 2.5e4, 1.0e4, 3.0e2, 9.0e4], zip(edges[:-1], edges[1:])):
+            flat[a:b] = v
+    else:
+        flat[:] = np.array([5.0e3, 1.0e4, 2.0e4])[np.arange(n) % 3]
+    c["temp"] = flat.reshape(N, N, N)
+    dev = torch.device("cuda", 0)
+    chem = [c[k] for k in CHEM_KEYS]
+    stream = torch.cuda.current_stream().cuda_stream
+    asora.device_init(N, 8, 0, 1)
+    try:
+        t = {k: torch.from_numpy(c[k].ravel().copy()).to(dev) for k in GRID_KEYS}
+        cf, _, _ = asora.global_pass_dev(c["dt"], *[t[k].data_ptr() for k in GRID_KEYS], *chem, N, stream)
+        torch.cuda.synchronize()
+        whole = {k: t[k].cpu().numpy() for k in ("xh_av", "xh_intermed")}
+        for lo in (0, n - M ** 3):  # first cells of their lanes / second cells of their lanes
+            u = {k: torch.from_numpy(c[k].ravel()[lo:lo + M ** 3].copy()).to(dev) for k in GRID_KEYS}
+            asora.global_pass_dev(c["dt"], *[u[k].data_ptr() for k in GRID_KEYS], *chem, M, stream)
+            torch.cuda.synchronize()
+            for k in ("xh_av", "xh_intermed"):
+                assert np.array_equal(u[k].cpu().numpy(), whole[k][lo:lo + M ** 3]), (temperature, lo, k)
+    finally:
+        asora.device_close()
+    xa, xi = c["xh_av"].copy(), c["xh_intermed"].copy()
+    cf_ref = port_oracle.global_pass(c["dt"], c["ndens"], c["temp"], c["xh"], xa, xi, c["phi_ion"], c["clump"], *chem)
+    assert cf == cf_ref
+    # (1.4e6 random cells, up to 400 fixed-point iterations each: the last-digit differences of the device library's
+    # exp / pow reach 3e-12 here, 1e-12 on the 6e4 cells of the tests above; north_star's bar on xHII is 1e-8)
+    assert np.max(np.abs(whole["xh_av"] - xa.ravel())) <= 2e-11
+    assert np.max(np.abs(whole["xh_intermed"] - xi.ravel())) <= 2e-11
+
+
 @pytest.mark.parametrize("skip_unobserved", [0, 1])
 def test_evolve_step_vs_golden(golden_dir, skip_unobserved):
     """One full evolve step through pyc2ray_amd.evolve.evolve3D (device-resident loop); also with the
