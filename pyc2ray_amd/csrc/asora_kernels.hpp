@@ -488,6 +488,11 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
 // ------------------------------------------------------------------------------------------
 // chunks per wave per phase.  Measured on the 256^3 / R = 60 sweep (4 waves per SIMD, ms per 1e4 sources):
 // 1: 135, 2: 121 (no spills), 3: 122, 4: 292 (spills); with the branch-free fast path: 2: 100, 3: 103
+// Workgroups of at least this many threads run their two halves half a phase apart (STAG in sweep_tab_kernel); 1 << 30: never
+#ifndef ASORA_STAGGER_MIN_THREADS
+#define ASORA_STAGGER_MIN_THREADS 1024
+#endif
+
 #ifndef ASORA_PHASE_CHUNKS
 #define ASORA_PHASE_CHUNKS 2
 #endif
@@ -619,10 +624,17 @@ __device__ __forceinline__ PhaseDesc phase_next(PhaseDesc d, const PlaneInfo *pl
 // list A (rate-producing) followed by list B -- are ONE sequence cut into 64-cell chunks, taken from the last
 // chunk down; the chunk that straddles the two lists counts as rate-producing (its B lanes never fire).
 // rates: wave-uniform, the chunk holds cells of list A; isA: this lane's cell is one of them.
-template <int NW, int QS>
+// SP != 0 (staggered halves, see sweep_tab_kernel): the first NW/2 waves take the first NW/2 * SP chunks of the phase,
+// the other half the rest (SP = chunks per wave per phase).
+template <int NW, int SP>
+__device__ __forceinline__ int slot_chunk(const PhaseDesc &d, int wave, int q) {  // wave-uniform
+    if (SP) return d.jbase + (wave >= NW / 2 ? (NW / 2) * SP + (wave - NW / 2) : wave) + q * (NW / 2);
+    return d.jbase + wave + q * NW;
+}
+template <int NW, int QS, int SP = 0>
 __device__ __forceinline__ uint32_t slot_index(const PhaseDesc &d, int wave, int q, int lane, bool &valid, bool &isA,
                                                bool &rates) {
-    const int jj = d.jbase + wave + q * NW;  // wave-uniform
+    const int jj = slot_chunk<NW, SP>(d, wave, q);
     const int c = d.nchunk - 1 - jj;
     const int i = (c * 64 + lane) >> QS;  // (the low QS bits of the lane number select the quadrant)
     rates = c < d.nchunkA;
@@ -630,10 +642,10 @@ __device__ __forceinline__ uint32_t slot_index(const PhaseDesc &d, int wave, int
     valid = d.valid && (jj < d.nchunk) && (i < d.cntT);
     return (uint32_t)(valid ? i : 0);
 }
-template <int NW, int QS>
+template <int NW, int QS, int SP = 0>
 __device__ __forceinline__ uint32_t slot_index(const PhaseDesc &d, int wave, int q, int lane, bool &valid, bool &isA) {
     bool rates;
-    return slot_index<NW, QS>(d, wave, q, lane, valid, isA, rates);
+    return slot_index<NW, QS, SP>(d, wave, q, lane, valid, isA, rates);
 }
 
 // The sweep is latency-bound (rocprofv3: waves wait 73 % of their cycles; an ablation without the
@@ -683,6 +695,17 @@ void sweep_tab_kernel(SweepArgs A) {
     static_assert(QSHIFT == 0 || QSHIFT == 2 || QSHIFT == 3, "1, 4 or 8 sectors per workgroup");
     static_assert(SSHIFT == 0 || (QUAD && QSHIFT + SSHIFT <= 6), "source packing rides on the multi-sector kernels");
     constexpr int QS = QSHIFT + SSHIFT;  // log2 of the lanes that share a cell
+    // STAG (large workgroups, one or two per CU): the two halves of the workgroup run half a phase apart -- while one
+    // half interpolates (a latency-bound dependent chain per cell) the other computes its rates (throughput-bound):
+    //     first half :  I(k)  | W R(k) | I(k+1)  | W R(k+1) | ...          I: staging reads + interpolation
+    //     second half:        | I(k)   | W R(k)  | I(k+1)   | ...          W: staging writes, R: rates + atomics
+    // ("|" = workgroup barrier; the second half passes one barrier before it starts, the first half one after it ends).
+    // The first half's chunks of a phase precede the second half's in the plane's sequence, so the in-place order holds:
+    // what a half reads while the other writes lies below the cells being written (see the barriers below).  At a
+    // plane change each half passes one more barrier before its first interpolation -- the last writes of the plane
+    // before are the other half's -- and the first half rebuilds the interpolation tables in that slot.
+    constexpr bool STAG = LDS_STAGE && !QUAD && THREADS >= ASORA_STAGGER_MIN_THREADS;
+    constexpr int SP = STAG ? P : 0;
     constexpr int NQ = 1 << QSHIFT, NSRC = 1 << SSHIFT, NS = QUAD ? 2 : 1;  // sectors, sources per wave; sign sets per table
     static_assert(!QUAD || LDS_STAGE, "the four-quadrant kernel stages in LDS");
     const double max_coldensh = (double)2e30f;  // raytracing.f90:368
@@ -773,7 +796,7 @@ void sweep_tab_kernel(SweepArgs A) {
 #pragma unroll
         for (int q = 0; q < P; q++) {
             bool v, ia;
-            meta_c[q] = at_byte(A.cell_meta, (d0.off + slot_index<NW, QS>(d0, wave, q, lane, v, ia)) * 8u);
+            meta_c[q] = at_byte(A.cell_meta, (d0.off + slot_index<NW, QS, SP>(d0, wave, q, lane, v, ia)) * 8u);
         }
 
         // (the previous task's last barrier guarantees nobody still reads the arrays below)
@@ -803,11 +826,11 @@ void sweep_tab_kernel(SweepArgs A) {
         // interpolation offsets of plane n for every row / column of every source of the group
         // ... of rows / columns 0 .. nlim only (plane n has none beyond min(n, W - 1)): entry i -> (table, sign set,
         // source, offset) with the offsets padded to a power of two, so that small planes cost one short pass
-        auto fill_offsets = [&](double alam, int nlim) {
+        auto fill_offsets = [&](double alam, int nlim, int nthreads = THREADS) {  // (threads 0 .. nthreads-1 call it)
             const int nl = min(nlim, W - 1);
             const int sh = 32 - __clz(nl);  // 1 << sh > nl
             constexpr int NSETS = NS * NSRC;
-            for (int i = tid; i < (2 * NSETS) << sh; i += THREADS) {
+            for (int i = tid; i < (2 * NSETS) << sh; i += nthreads) {
                 const int o = i & ((1 << sh) - 1), st = i >> sh;
                 if (o > nl) continue;
                 const bool is_u = st < NSETS;
@@ -847,7 +870,7 @@ void sweep_tab_kernel(SweepArgs A) {
 #pragma unroll
             for (int q = 0; q < P; q++) {
                 bool v, ia;
-                const uint32_t idx = slot_index<NW, QS>(d0, wave, q, lane, v, ia);
+                const uint32_t idx = slot_index<NW, QS, SP>(d0, wave, q, lane, v, ia);
                 const uint32_t a = meta_c[q].x & META_COORD_MASK, b = (meta_c[q].x >> META_COORD_BITS) & META_COORD_MASK;
                 g_c[q] = baseP + (uint32_t)rowU[set_u + a] + (uint32_t)colV[set_v + b];
                 geo_c[q] = at_byte(A.cell_geo, (d0.off + idx) * 16u);
@@ -855,7 +878,17 @@ void sweep_tab_kernel(SweepArgs A) {
             }
         }
 
+        const bool second_half = STAG && wave >= NW / 2;
+        int plane_prev = d0.n;
+        if (STAG && second_half) phase_barrier<LDS_STAGE>();  // half a phase behind
         while (d0.valid) {
+            if (STAG && d0.n != plane_prev) {
+                // first phase of a plane: the last writes of the plane before are the other half's and land in this slot;
+                // the first half rebuilds the interpolation tables meanwhile (nobody interpolates the old plane any more)
+                if (!second_half) fill_offsets(planes[d0.n].alam, d0.n, THREADS / 2);
+                phase_barrier<LDS_STAGE>();
+                plane_prev = d0.n;
+            }
             // ---- cell coordinates of the next phase: in flight during this phase's interpolation ------
             // (unconditional -- past the last phase slot_index gives cell 0 of the last plane -- so that the
             // compiler counts the operations in flight exactly, see make_rsrc)
@@ -863,7 +896,7 @@ void sweep_tab_kernel(SweepArgs A) {
 #pragma unroll
             for (int q = 0; q < P; q++) {
                 bool v, ia;
-                idx_n[q] = d1.off + slot_index<NW, QS>(d1, wave, q, lane, v, ia);
+                idx_n[q] = d1.off + slot_index<NW, QS, SP>(d1, wave, q, lane, v, ia);
                 meta_n[q] = at_byte(A.cell_meta, idx_n[q] * 8u);
             }
 
@@ -875,7 +908,7 @@ void sweep_tab_kernel(SweepArgs A) {
             // one slot: 4-point interpolation, new column density and its weight (raytracing.f90:662-813)
             auto interp = [&](const int q, const bool plane1, const bool with_cdh) __attribute__((always_inline)) {
                 bool valid, isA, rates;
-                (void)slot_index<NW, QS>(d0, wave, q, lane, valid, isA, rates);
+                (void)slot_index<NW, QS, SP>(d0, wave, q, lane, valid, isA, rates);
                 const uint2 m = meta_c[q];
                 const uint32_t a = m.x & META_COORD_MASK, b = (m.x >> META_COORD_BITS) & META_COORD_MASK;
                 const double2 du = du_tab[set_u + a], dv = dv_tab[set_v + b];
@@ -920,7 +953,7 @@ void sweep_tab_kernel(SweepArgs A) {
             // the barrier its workgroup waits at goes first (0.6 %)
             __builtin_amdgcn_s_setprio(0);
             const int nchunks = d0.nchunk;
-            const bool all_on = d0.jbase + wave + (P - 1) * NW < nchunks && n != 1 && !cdh;
+            const bool all_on = slot_chunk<NW, SP>(d0, wave, P - 1) < nchunks && n != 1 && !cdh;
 #if defined(ASORA_ABL_NORATES) || defined(ASORA_NO_RATE_BATCH)
             const bool all_rates = false;
 #else
@@ -928,7 +961,7 @@ void sweep_tab_kernel(SweepArgs A) {
             // (... and so it does -- 20 to 37 registers -- in the packed kernels, whose lanes carry their own source)
             // ... and in the single-wave multi-sector kernels (R <~ 12), where batching costs 2 - 8 %)
             const bool all_rates = !HEAT && !PACK && !(QUAD && THREADS == 64) && all_on &&
-                                   d0.nchunk - 1 - (d0.jbase + wave) < d0.nchunkA;
+                                   d0.nchunk - 1 - slot_chunk<NW, SP>(d0, wave, 0) < d0.nchunkA;
 #endif
             if (all_on) {
                 // the usual phase: every slot of this wave is occupied -> ONE basic block, so that the scheduler
@@ -950,7 +983,7 @@ void sweep_tab_kernel(SweepArgs A) {
                     cdo[q] = 0.0;
                     wo[q] = 0.0;
                     cin[q] = 0.0;
-                    if (d0.jbase + wave + q * NW < nchunks) interp(q, n == 1, true);  // wave-uniform
+                    if (slot_chunk<NW, SP>(d0, wave, q) < nchunks) interp(q, n == 1, true);  // wave-uniform
                 }
             }
             // ---- geometry + neutral density of the next phase: in flight during this phase's rates ------
@@ -987,10 +1020,20 @@ void sweep_tab_kernel(SweepArgs A) {
             bool all_live = true;
 #pragma unroll
             for (int q = 0; q < P; q++) all_live = all_live && slot_live[q];
+            const bool batch = all_rates && all_live;
+            if (STAG) {
+                // Both halves have read what this half is about to overwrite: the other half's current interpolation
+                // is of LATER chunks (second half) or started behind this half's previous barrier (first half) --
+                // and what it reads meanwhile lies below this half's cells.
+                phase_barrier<LDS_STAGE>();
+#pragma unroll
+                for (int q = 0; q < P; q++)
+                    if (woff[q] >= 0) C.stg.st((uint32_t)woff[q], cdo[q], wo[q]);
+            }
             __builtin_amdgcn_s_setprio(2);
             // rates: when every slot of the wave holds rate-producing cells, all of them together (their log10 /
             // look-up chains interleave); otherwise one slot at a time
-            if (all_rates && all_live) {
+            if (batch) {
                 RatePrep rp[P];
                 RateLoads rl[P];
 #pragma unroll
@@ -1028,18 +1071,20 @@ void sweep_tab_kernel(SweepArgs A) {
                 (void)llvm_amdgcn_raw_buffer_atomic_fadd_f64(ph[q], phi_rs, off, 0, 0);
                 if (HEAT) (void)llvm_amdgcn_raw_buffer_atomic_fadd_f64(ht[q], heat_rs, off, 0, 0);
             }
-            phase_barrier<LDS_STAGE>();  // every wave has read the old values it needs
+            if (!STAG) {  // (STAG: written behind the barrier above; the tables follow at the top of the next plane)
+                phase_barrier<LDS_STAGE>();  // every wave has read the old values it needs
 #pragma unroll
-            for (int q = 0; q < P; q++)
-                if (woff[q] >= 0) C.stg.st((uint32_t)woff[q], cdo[q], wo[q]);
-            if (d1.n != n)  // last phase of this plane: interpolation offsets of the next one
-                fill_offsets(planes[min(n + 1, A.nplanes - 1)].alam, n + 1);
+                for (int q = 0; q < P; q++)
+                    if (woff[q] >= 0) C.stg.st((uint32_t)woff[q], cdo[q], wo[q]);
+                if (d1.n != n)  // last phase of this plane: interpolation offsets of the next one
+                    fill_offsets(planes[min(n + 1, A.nplanes - 1)].alam, n + 1);
+            }
             // New values visible -- to the NEXT PLANE.  Within a plane the next phase takes lower chunks of the sequence:
             // it reads old values at positions below everything this phase writes (A cells read A cells only; inside a
             // list positions fall with the sequence) and writes only behind its own barrier, so with the staging in LDS
             // (one program order per wave) no second barrier is needed between the phases of a plane.
 #ifndef ASORA_TWO_BARRIERS
-            if (!LDS_STAGE || d1.n != n)
+            if (STAG || !LDS_STAGE || d1.n != n)
 #endif
             phase_barrier<LDS_STAGE>();
             // ---- rotate the pipeline --------------------------------------------------------------
@@ -1053,6 +1098,7 @@ void sweep_tab_kernel(SweepArgs A) {
                 g_c[q] = g_n[q];
             }
         }
+        if (STAG && !second_half) phase_barrier<LDS_STAGE>();  // (the second half's last slot)
     }
 }
 

@@ -73,6 +73,37 @@ def test_bench_R100_wide_workgroups_vs_oracle(asora, port_oracle, ref_oracle):
     assert m.sum() > 4_000_000 and np.array_equal(cdh[m], o["coldensh_out"][m])
 
 
+@pytest.mark.parametrize("compact", [0, 1])
+def test_staggered_halves_equal_the_256_thread_kernel(asora, compact):
+    """Workgroups of 512 and 1024 threads run their two halves half a phase apart (asora_kernels.hpp, STAG): one half
+    interpolates while the other writes and computes rates.  At 192^3 / R = 80.5 the planes hold up to 100 chunks, so
+    both halves are busy and the slots really overlap; the 256-thread kernel (all waves in step) must give the same
+    bits for a single source -- rates, heating rates, column density -- and so must skip_saturated's variants."""
+    N = 192
+    c = cases._base(N, 80.5, 3.0 * MPC / 200, [[150, 7, 101]], [3.0e4], ndens=cases.lognormal_density(N, 11, smooth=2.0),
+                    xh=np.full((N, N, N), 0.98), table_kw=dict(temp=1e5, numtau=20000))  # tau ~ 8 across the sphere
+    out = {}
+    for threads in (256, 512, 1024):
+        for sat in (0, 1):
+            asora.set_option("wg_threads", threads)
+            asora.set_option("compact_staging", compact)
+            asora.set_option("skip_saturated", sat)
+            try:
+                out[threads, sat] = run_hip(asora, c, heat=True)
+                info = asora.last_launch_info()
+            finally:
+                asora.set_option("wg_threads", 0)
+                asora.set_option("compact_staging", 0)
+                asora.set_option("skip_saturated", 0)
+            assert info["block"] == threads and info["staging"] == ("lds-compact" if compact else "lds"), info
+    phi0, cdh0, heat0 = out[256, 0]
+    assert (phi0 > 0).sum() > 1_000_000 and (cdh0 > 0).sum() > 3_000_000
+    for key, (phi, cdh, heat) in out.items():
+        assert np.array_equal(cdh, cdh0), key
+        assert np.array_equal(phi, phi0), key
+        assert np.array_equal(heat, heat0), key
+
+
 def test_fullbox_256_single_source_global_staging(asora, port_oracle, ref_oracle):
     """configs[0]-like: one source, uniform 256^3, R beyond the box -> the staged entries no longer fit
     in LDS and live in global memory (the kernel's other staging path)."""
