@@ -179,11 +179,13 @@ int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_i
  * of LDS per entry; 0 = automatic: when the pairs would allow at most one workgroup per CU; -1: never),
  * "quad_kernel" (four sign quadrants of a pyramid per workgroup, for small radii; 0 = automatic: up to
  * "quad_max_entries" staged entries per quadrant, default 1210, i.e. R <~ 46 cells; 1: whenever the quadrants share
- * their geometry; 2: eight octants of an axis per workgroup, automatic up to "oct_max_entries", default 64, R <~ 8;
+ * their geometry; 2: eight octants of an axis per workgroup, automatic up to "oct_max_entries", default 120, R <~ 12;
  * -1: never),
  * "src_pack" (the multi-sector kernels take 1 << src_pack consecutive sources of the sweep order per workgroup, side by
  * side in the lanes of a wavefront: 0 = automatic, while four 256-thread workgroups of that kind fit on a CU --
  * "pack_max_lds" bytes each, default 40 KiB, R <~ 12 cells; 2 / 3: four / eight sources; -1: never),
+ * "stride_residue" (multi-sector kernels: -1 = pad the per-sector staging arrays so that the lanes of a cell hit different
+ * LDS banks, while the workgroups per CU stay the same; -2: the geometry's size; >= 0: that size modulo 32),
  * "source_order" (see asora_source_order),
  * "skip_unobserved" (1: cells outside the R-sphere -- never upwind of a cell inside it -- are swept only for
  * the source whose column density is exported; phi and coldensh_out unchanged, ~27 % less time at 256^3 / R = 60;

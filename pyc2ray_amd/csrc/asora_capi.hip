@@ -91,6 +91,7 @@ struct State {
     int lds_pad = 0;              // option "lds_pad": extra dynamic LDS per workgroup (occupancy experiments)
     int wg_threads = 0;           // option "wg_threads": workgroup size of the table-driven kernel, 256/512/1024 (0: automatic)
     int quad_kernel = 0;          // option "quad_kernel": four quadrants per workgroup (0: automatic, 1: whenever possible, -1: never)
+    int stride_residue = -1;
     int oct_max_entries = 120;    // option "oct_max_entries": automatic choice of eight octants per workgroup up to this many entries (R <~ 12)
     int quad_max_entries = 1210;  // option "quad_max_entries": automatic choice up to this many staged entries per quadrant (R <~ 46)
     int last_quad = 0;
@@ -642,7 +643,23 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             use_lds = true;
         }
     }
-    const size_t lds = (use_lds ? lds_stage : 0) + lds_fixed + (size_t)S.lds_pad;
+    size_t lds = (use_lds ? lds_stage : 0) + lds_fixed + (size_t)S.lds_pad;
+    // Multi-sector kernels: the lanes of a cell read the same position of 4 / 8 staging arrays, E entries apart.  With
+    // E a multiple of 8 (16) the four (eight) reads of a cell fall into the same LDS banks; E = 4 mod 8 (2 mod 4) lets
+    // the 16 lanes of one LDS pass tile its banks.  Measured at 1e4 sources: R = 25 (E = 400) 9.12 -> 8.63 ms, R = 30
+    // 14.66 -> 14.39 ms; a forced multiple of 32 costs 2 - 6 % at R = 28 ... 45.  The array is padded only while the
+    // workgroups per CU stay the same (option "stride_residue": -1 this rule, -2 as the geometry gives it, >= 0: E modulo 32).
+    if (use_tab && use_lds && quad && !sshift && S.stride_residue != -2) {
+        const int mod = S.stride_residue >= 0 ? 32 : (qshift == 3 ? 4 : 8);
+        const int want = S.stride_residue >= 0 ? S.stride_residue % 32 : (qshift == 3 ? 2 : 4);
+        const int delta = ((want - A.cw_entries) % mod + mod) % mod;
+        const size_t lds2 = lds + (size_t)delta * ((size_t)1 << qshift) * (compact ? 8 : 16);
+        auto per_cu = [&](size_t b) { return (size_t)S.max_lds / ((b + 1023) & ~(size_t)1023); };
+        if (delta && lds2 <= (size_t)S.max_lds && per_cu(lds2) == per_cu(lds)) {
+            A.cw_entries += delta;
+            lds = lds2;
+        }
+    }
     if (lds > (size_t)S.max_lds) return fail(13, "asora_do_all_sources: per-row tables (%zu B) exceed LDS", lds);
 
     S.timed = false;
@@ -944,7 +961,7 @@ int asora_device_close(void) {
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     State fresh;  // options and the last launch record survive a close
-    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.skip_saturated = S.skip_saturated; fresh.compact_staging = S.compact_staging; fresh.quad_kernel = S.quad_kernel; fresh.quad_max_entries = S.quad_max_entries; fresh.oct_max_entries = S.oct_max_entries; fresh.last_quad = S.last_quad; fresh.src_pack = S.src_pack; fresh.pack_max_lds = S.pack_max_lds; fresh.pack_max_entries = S.pack_max_entries; fresh.max_table_cells = S.max_table_cells;
+    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.skip_saturated = S.skip_saturated; fresh.compact_staging = S.compact_staging; fresh.quad_kernel = S.quad_kernel; fresh.quad_max_entries = S.quad_max_entries; fresh.oct_max_entries = S.oct_max_entries; fresh.stride_residue = S.stride_residue; fresh.last_quad = S.last_quad; fresh.src_pack = S.src_pack; fresh.pack_max_lds = S.pack_max_lds; fresh.pack_max_entries = S.pack_max_entries; fresh.max_table_cells = S.max_table_cells;
     fresh.last_tab = S.last_tab; fresh.last_grid = S.last_grid; fresh.last_block = S.last_block;
     fresh.last_lds = S.last_lds; fresh.last_is_lds = S.last_is_lds;
     const int dev = S.device;
@@ -1256,6 +1273,7 @@ int asora_set_option(const char *name, long long value) {
     else if (!std::strcmp(name, "quad_kernel")) S.quad_kernel = (int)value;
     else if (!std::strcmp(name, "quad_max_entries")) S.quad_max_entries = (int)value;
     else if (!std::strcmp(name, "oct_max_entries")) S.oct_max_entries = (int)value;
+    else if (!std::strcmp(name, "stride_residue")) S.stride_residue = (int)value;
     else if (!std::strcmp(name, "compact_staging")) S.compact_staging = (int)value;
     else if (!std::strcmp(name, "src_pack")) S.src_pack = (int)value;
     else if (!std::strcmp(name, "pack_max_lds")) S.pack_max_lds = (int)value;
