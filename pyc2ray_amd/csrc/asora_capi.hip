@@ -649,11 +649,13 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     // the 16 lanes of one LDS pass tile its banks.  Measured at 1e4 sources: R = 25 (E = 400) 9.12 -> 8.63 ms, R = 30
     // 14.66 -> 14.39 ms; a forced multiple of 32 costs 2 - 6 % at R = 28 ... 45.  The array is padded only while the
     // workgroups per CU stay the same (option "stride_residue": -1 this rule, -2 as the geometry gives it, >= 0: E modulo 32).
-    if (use_tab && use_lds && quad && !sshift && S.stride_residue != -2) {
+    // (Packed sources: 32 - 64 arrays, one per lane of a cell; only a multiple of 16 hurts -- R = 5: 0.273 -> 0.326 ms.)
+    if (use_tab && use_lds && quad && S.stride_residue != -2) {
         const int mod = S.stride_residue >= 0 ? 32 : (qshift == 3 ? 4 : 8);
         const int want = S.stride_residue >= 0 ? S.stride_residue % 32 : (qshift == 3 ? 2 : 4);
-        const int delta = ((want - A.cw_entries) % mod + mod) % mod;
-        const size_t lds2 = lds + (size_t)delta * ((size_t)1 << qshift) * (compact ? 8 : 16);
+        int delta = ((want - A.cw_entries) % mod + mod) % mod;
+        if (sshift && S.stride_residue < 0) delta = A.cw_entries % 16 == 0 ? 1 : 0;
+        const size_t lds2 = lds + (size_t)delta * ((size_t)1 << (qshift + sshift)) * (compact ? 8 : 16);
         auto per_cu = [&](size_t b) { return (size_t)S.max_lds / ((b + 1023) & ~(size_t)1023); };
         if (delta && lds2 <= (size_t)S.max_lds && per_cu(lds2) == per_cu(lds)) {
             A.cw_entries += delta;
