@@ -792,11 +792,11 @@ void sweep_tab_kernel(SweepArgs A) {
         d0.n = 1; d0.jbase = 0; d0.off = 0; d0.cntA = d0.cntT = d0.nchunkA = d0.nchunk = 0;
         phase_load_plane<QS>(d0, planes, nmax, rate_only);
         d1 = phase_next<NW * P, QS>(d0, planes, nmax, rate_only);
-        uint2 meta_c[P], meta_n[P];
+        uint2 meta_a[P], meta_b[P];  // (the two register sets of the phase pipeline, see the loop)
 #pragma unroll
         for (int q = 0; q < P; q++) {
             bool v, ia;
-            meta_c[q] = at_byte(A.cell_meta, (d0.off + slot_index<NW, QS, SP>(d0, wave, q, lane, v, ia)) * 8u);
+            meta_a[q] = at_byte(A.cell_meta, (d0.off + slot_index<NW, QS, SP>(d0, wave, q, lane, v, ia)) * 8u);
         }
 
         // (the previous task's last barrier guarantees nobody still reads the arrays below)
@@ -862,26 +862,31 @@ void sweep_tab_kernel(SweepArgs A) {
         __syncthreads();
 
         // geometry + neutral density of the first phase (rowU / colV are ready now)
-        double2 geo_c[P], geo_n[P];
-        double nhi_c[P], nhi_n[P];
-        uint32_t g_c[P], g_n[P];
+        double2 geo_a[P], geo_b[P];
+        double nhi_a[P], nhi_b[P];
+        uint32_t g_a[P], g_b[P];
         {
             const uint32_t baseP = (uint32_t)wrap(p0 + sp * d0.n, N) * strideP;
 #pragma unroll
             for (int q = 0; q < P; q++) {
                 bool v, ia;
                 const uint32_t idx = slot_index<NW, QS, SP>(d0, wave, q, lane, v, ia);
-                const uint32_t a = meta_c[q].x & META_COORD_MASK, b = (meta_c[q].x >> META_COORD_BITS) & META_COORD_MASK;
-                g_c[q] = baseP + (uint32_t)rowU[set_u + a] + (uint32_t)colV[set_v + b];
-                geo_c[q] = at_byte(A.cell_geo, (d0.off + idx) * 16u);
-                nhi_c[q] = at_byte(nhi, g_c[q] * 8u);
+                const uint32_t a = meta_a[q].x & META_COORD_MASK, b = (meta_a[q].x >> META_COORD_BITS) & META_COORD_MASK;
+                g_a[q] = baseP + (uint32_t)rowU[set_u + a] + (uint32_t)colV[set_v + b];
+                geo_a[q] = at_byte(A.cell_geo, (d0.off + idx) * 16u);
+                nhi_a[q] = at_byte(nhi, g_a[q] * 8u);
             }
         }
 
         const bool second_half = STAG && wave >= NW / 2;
         int plane_prev = d0.n;
         if (STAG && second_half) phase_barrier<LDS_STAGE>();  // half a phase behind
-        while (d0.valid) {
+        // One phase: works the cells of phase d0 from the register set (meta_c, geo_c, nhi_c, g_c), loads the set of
+        // phase d1 into (meta_n, geo_n, nhi_n, g_n), and steps d0 / d1.  The loop below calls it with the two sets in
+        // alternating roles, so no register moves from phase to phase (18 per wave and phase otherwise).
+        auto one_phase = [&](uint2 (&meta_c)[P], double2 (&geo_c)[P], double (&nhi_c)[P], uint32_t (&g_c)[P],
+                             uint2 (&meta_n)[P], double2 (&geo_n)[P], double (&nhi_n)[P],
+                             uint32_t (&g_n)[P]) __attribute__((always_inline)) {
             if (STAG && d0.n != plane_prev) {
                 // first phase of a plane: the last writes of the plane before are the other half's and land in this slot;
                 // the first half rebuilds the interpolation tables meanwhile (nobody interpolates the old plane any more)
@@ -953,7 +958,11 @@ void sweep_tab_kernel(SweepArgs A) {
             // the barrier its workgroup waits at goes first (0.6 %)
             __builtin_amdgcn_s_setprio(0);
             const int nchunks = d0.nchunk;
+#ifdef ASORA_ABL_GENERIC_PHASE
+            const bool all_on = false;  // ablation build: every phase through the per-slot path
+#else
             const bool all_on = slot_chunk<NW, SP>(d0, wave, P - 1) < nchunks && n != 1 && !cdh;
+#endif
 #if defined(ASORA_ABL_NORATES) || defined(ASORA_NO_RATE_BATCH)
             const bool all_rates = false;
 #else
@@ -1087,15 +1096,34 @@ void sweep_tab_kernel(SweepArgs A) {
             if (STAG || !LDS_STAGE || d1.n != n)
 #endif
             phase_barrier<LDS_STAGE>();
-            // ---- rotate the pipeline --------------------------------------------------------------
+            // ---- step the pipeline ------------------------------------------------------------------
             d0 = d1;
             d1 = phase_next<NW * P, QS>(d1, planes, nmax, rate_only);
+        };
+        // (Not for the unpacked eight-octant kernel: its registers are spoken for, the second copy of the phase spills
+        // 30 - 40 of them -- R = 10 ... 12: 11 - 13 % slower; everywhere else +0.5 ... 2.7 %.)
+#ifdef ASORA_NO_PHASE_UNROLL
+        constexpr bool TWO_SETS = false;
+#else
+        constexpr bool TWO_SETS = !(OCT && !PACK);
+#endif
+        if (TWO_SETS) {
+            for (;;) {
+                if (!d0.valid) break;
+                one_phase(meta_a, geo_a, nhi_a, g_a, meta_b, geo_b, nhi_b, g_b);
+                if (!d0.valid) break;
+                one_phase(meta_b, geo_b, nhi_b, g_b, meta_a, geo_a, nhi_a, g_a);
+            }
+        } else {
+            while (d0.valid) {
+                one_phase(meta_a, geo_a, nhi_a, g_a, meta_b, geo_b, nhi_b, g_b);
 #pragma unroll
-            for (int q = 0; q < P; q++) {
-                meta_c[q] = meta_n[q];
-                geo_c[q] = geo_n[q];
-                nhi_c[q] = nhi_n[q];
-                g_c[q] = g_n[q];
+                for (int q = 0; q < P; q++) {
+                    meta_a[q] = meta_b[q];
+                    geo_a[q] = geo_b[q];
+                    nhi_a[q] = nhi_b[q];
+                    g_a[q] = g_b[q];
+                }
             }
         }
         if (STAG && !second_half) phase_barrier<LDS_STAGE>();  // (the second half's last slot)
