@@ -394,6 +394,37 @@ def test_source_packing_equals_sector_kernel(asora, golden_dir, name, opts):
             asora.set_option(k, {"source_order": 2}.get(k, 0))
 
 
+@pytest.mark.parametrize("opts", [dict(quad_kernel=1), dict(quad_kernel=2), dict(quad_kernel=1, wg_threads=256, compact_staging=1),
+                                  dict(quad_kernel=2, src_pack=2)])
+@pytest.mark.parametrize("name", ["multi16_unequal", "rcut7p3"])
+def test_staging_array_stride_is_free(asora, golden_dir, name, opts):
+    """The multi-sector kernels keep one staging array per sector (and source), E entries apart; the host pads E so that
+    the lanes of a cell hit different LDS banks (option stride_residue: -1 automatic, -2 none, >= 0 forced modulo 32).
+    The padding entries are never addressed: every choice gives the same bits."""
+    c = load_golden(golden_dir, name)
+    for k, v in opts.items():
+        asora.set_option(k, v)
+    out, lds = {}, {}
+    try:
+        for sr in (-2, -1, 0, 5, 31):
+            asora.set_option("stride_residue", sr)
+            out[sr] = (run_hip(asora, c, heat=bool(c["heat_valid"]), num_src=1), run_hip(asora, c))
+            info = asora.last_launch_info()
+            assert info["quad"], info
+            lds[sr] = info["lds_bytes"]
+    finally:
+        asora.set_option("stride_residue", -1)
+        for k in opts:
+            asora.set_option(k, 0)
+    print(name, opts, "LDS bytes by stride_residue:", lds)  # (small arrays: a pad that changes the workgroups per CU is not applied)
+    one, full = out[-2]
+    for sr, (o, f) in out.items():
+        for a, b in zip(o, one):
+            assert (a is None and b is None) or np.array_equal(a, b), sr
+        assert np.array_equal(f[1], full[1]), sr
+        assert np.allclose(f[0], full[0], rtol=1e-13, atol=0), sr
+
+
 @pytest.mark.parametrize("name", ["multi16_unequal", "rcut7p3", "lognormal48", "corner33"])
 def test_skip_unobserved_cells(asora, golden_dir, name):
     """Option skip_unobserved (off by default; never used by bench.py): cells outside the R-sphere are not
