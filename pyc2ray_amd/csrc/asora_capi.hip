@@ -54,7 +54,34 @@ int fail(int code, const char *fmt, ...) {
                         __LINE__);                                                                        \
     } while (0)
 
+// Tuning options (asora_set_option) and the record of the last launch (asora_last_launch_info): both survive a
+// close / re-init of the device.
+struct Options {
+    int source_order = 2;         // option "source_order": 0 as given, 1 Morton, 2 Hilbert curve
+    int lds_stage_limit = 0;      // option "lds_stage_limit": larger staging arrays go to global memory (0: automatic)
+    int lds_pad = 0;              // option "lds_pad": extra dynamic LDS per workgroup (occupancy experiments)
+    int wg_threads = 0;           // option "wg_threads": workgroup size of the table-driven kernel, 256/512/1024 (0: automatic)
+    int quad_kernel = 0;          // option "quad_kernel": four quadrants per workgroup (0: automatic, 1: whenever possible, -1: never)
+    int stride_residue = -1;      // option "stride_residue": entries between the sectors' staging arrays (-1: padded for the LDS banks, -2: as built, >= 0: modulo 32)
+    int oct_max_entries = 120;    // option "oct_max_entries": automatic choice of eight octants per workgroup up to this many entries (R <~ 12)
+    int quad_max_entries = 1210;  // option "quad_max_entries": automatic choice up to this many staged entries per quadrant (R <~ 46)
+    int src_pack = 0;             // option "src_pack": sources per workgroup of the multi-sector kernels as a shift (0: automatic, -1: one, 2: four, 3: eight)
+    int pack_max_lds = 40 * 1024; // option "pack_max_lds": automatic packing only while a workgroup's LDS stays below this (four 256-thread workgroups per CU)
+    int pack_max_entries = 64;    // option "pack_max_entries": ... and up to this many staged entries per sector (R <~ 8)
+    int compact_staging = 0;      // option "compact_staging": stage column densities only (0: automatic, 1: always, -1: never)
+    int skip_unobserved = 0;      // option "skip_unobserved": cells outside the R-sphere only for the exported column density
+    int skip_saturated = 0;       // option "skip_saturated": no rate evaluation behind optical depths beyond the table's end
+    int force_generic = 0;        // option "force_generic": always use the table-free kernel
+    long long max_table_cells = 48LL << 20;  // option "max_table_cells": beyond this the generic kernel runs
+};
+struct LaunchRecord {
+    int last_tab = 0;
+    int last_grid = 0, last_block = 0, last_lds = 0, last_is_lds = 1;
+};
+
 struct State {
+    Options opt;
+    LaunchRecord rec;
     bool init = false;
     int device = 0;
     int N = 0;
@@ -79,7 +106,6 @@ struct State {
     int staged_n = -1;            // the device copies hold the first staged_n sources of the caller's list ...
     int staged_order = -1;        // ... sorted with this "source_order"
     int staged_last = -1;         // position of the caller's source staged_n - 1 in the sweep order
-    int source_order = 2;         // option "source_order": 0 as given, 1 Morton, 2 Hilbert curve
     // geometry tables of the table-driven sweep (cached per (N, R, dr))
     asora::PlaneInfo *planes_dev = nullptr;
     uint2 *cell_meta_dev = nullptr;
@@ -87,24 +113,6 @@ struct State {
     int geo_N = 0, geo_nplanes = 0, geo_entries = 0, geo_vmap[8] = {0}, geo_nmax_rate = 0;
     double geo_R = -1.0, geo_dr = -1.0;
     bool geo_valid = false;
-    int lds_stage_limit = 0;      // option "lds_stage_limit": larger staging arrays go to global memory (0: automatic)
-    int lds_pad = 0;              // option "lds_pad": extra dynamic LDS per workgroup (occupancy experiments)
-    int wg_threads = 0;           // option "wg_threads": workgroup size of the table-driven kernel, 256/512/1024 (0: automatic)
-    int quad_kernel = 0;          // option "quad_kernel": four quadrants per workgroup (0: automatic, 1: whenever possible, -1: never)
-    int stride_residue = -1;
-    int oct_max_entries = 120;    // option "oct_max_entries": automatic choice of eight octants per workgroup up to this many entries (R <~ 12)
-    int quad_max_entries = 1210;  // option "quad_max_entries": automatic choice up to this many staged entries per quadrant (R <~ 46)
-    int last_quad = 0;
-    int src_pack = 0;             // option "src_pack": sources per workgroup of the multi-sector kernels as a shift (0: automatic, -1: one, 2: four, 3: eight)
-    int pack_max_lds = 40 * 1024; // option "pack_max_lds": automatic packing only while a workgroup's LDS stays below this (four 256-thread workgroups per CU)
-    int pack_max_entries = 64;    // option "pack_max_entries": ... and up to this many staged entries per sector (R <~ 8)
-    int last_pack = 0;
-    int compact_staging = 0;      // option "compact_staging": stage column densities only (0: automatic, 1: always, -1: never)
-    int skip_unobserved = 0;      // option "skip_unobserved": cells outside the R-sphere only for the exported column density
-    int skip_saturated = 0;       // option "skip_saturated": no rate evaluation behind optical depths beyond the table's end
-    int force_generic = 0;        // option "force_generic": always use the table-free kernel
-    long long max_table_cells = 48LL << 20;  // option "max_table_cells": beyond this the generic kernel runs
-    int last_tab = 0;
     double *log10_table = nullptr;  // asora_log10.hpp table
     // staging scratch for planes that do not fit in LDS
     double *gscratch = nullptr;
@@ -116,7 +124,6 @@ struct State {
     // timing / launch info
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    int last_grid = 0, last_block = 0, last_lds = 0, last_is_lds = 1;
     int max_lds = 65536;
     int num_cu = 256;
 };
@@ -416,9 +423,9 @@ void sweep_order(const int32_t *pos, int num_src, int N, int order, int *perm) {
 }
 
 int stage_sources(int num_src) {
-    if (S.staged_n == num_src && S.staged_order == S.source_order) return 0;
+    if (S.staged_n == num_src && S.staged_order == S.opt.source_order) return 0;
     std::vector<int> perm((size_t)std::max(num_src, 1));
-    sweep_order(S.host_pos.data(), num_src, S.N, S.source_order, perm.data());
+    sweep_order(S.host_pos.data(), num_src, S.N, S.opt.source_order, perm.data());
     std::vector<int32_t> pos(3 * (size_t)num_src);
     std::vector<double> flux((size_t)num_src);
     S.staged_last = -1;
@@ -436,7 +443,7 @@ int stage_sources(int num_src) {
         HIP_TRY(hipMemcpy(S.src_flux, flux.data(), flux.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     S.staged_n = num_src;
-    S.staged_order = S.source_order;
+    S.staged_order = S.opt.source_order;
     return 0;
 }
 
@@ -515,8 +522,8 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     const size_t lds_log = asora::LOG10_TABLE_DOUBLES * sizeof(double);  // log10 table, always in LDS
     const int nmaxmax = std::min(std::max(A.last_l, A.last_r), A.q_max);
     // the table-driven kernel needs 32-bit cell offsets, 10-bit in-plane coordinates and 16-bit staging positions
-    bool use_tab = !S.force_generic && S.cells < (1ULL << 28) && wmax < 1024 &&
-                   8 * geometry_cells_per_variant(A.q_max, std::max(A.last_l, A.last_r), nmaxmax) <= S.max_table_cells;
+    bool use_tab = !S.opt.force_generic && S.cells < (1ULL << 28) && wmax < 1024 &&
+                   8 * geometry_cells_per_variant(A.q_max, std::max(A.last_l, A.last_r), nmaxmax) <= S.opt.max_table_cells;
     if (use_tab && num_src > 0) {
         if (int rc2 = build_geometry(N, R, dr, A.q_max, A.last_l, A.last_r, st)) return rc2;
         if (S.geo_entries > 65535) use_tab = false;
@@ -528,18 +535,18 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         // ONE packed array of (column density, weight) pairs, updated in place, + per-row/column tables
         A.planes = S.planes_dev; A.cell_meta = S.cell_meta_dev; A.cell_geo = S.cell_geo_dev;
         A.nplanes = S.geo_nplanes; A.cw_entries = S.geo_entries;
-        A.rate_only = S.skip_unobserved ? 1 : 0; A.nmax_rate = S.geo_nmax_rate;
+        A.rate_only = S.opt.skip_unobserved ? 1 : 0; A.nmax_rate = S.geo_nmax_rate;
         for (int i = 0; i < 8; i++) A.vmap[i] = S.geo_vmap[i];
         // four-quadrant / eight-octant kernel (small radii): the sectors a workgroup takes side by side must share
         // their geometry variant (and, for the octants, their planes), and their staging arrays must fit in LDS
-        quad = S.quad_kernel >= 0 && num_src > 0 && S.lds_stage_limit <= 0;
+        quad = S.opt.quad_kernel >= 0 && num_src > 0 && S.opt.lds_stage_limit <= 0;
         for (int i = 2; i < 8; i++) quad = quad && S.geo_vmap[i] == S.geo_vmap[i & 1];
-        if (quad && S.quad_kernel == 0)  // automatic: small radii, and no workgroup size forced that the variant lacks
-            quad = A.cw_entries <= S.quad_max_entries &&
-                   (S.wg_threads == 0 || S.wg_threads == 64 || S.wg_threads == 128 || S.wg_threads == 256);
+        if (quad && S.opt.quad_kernel == 0)  // automatic: small radii, and no workgroup size forced that the variant lacks
+            quad = A.cw_entries <= S.opt.quad_max_entries &&
+                   (S.opt.wg_threads == 0 || S.opt.wg_threads == 64 || S.opt.wg_threads == 128 || S.opt.wg_threads == 256);
         qshift = quad ? 2 : 0;
         if (quad && A.q_max <= std::min(A.last_l, A.last_r) &&
-            (S.quad_kernel == 2 || (S.quad_kernel == 0 && A.cw_entries <= S.oct_max_entries)))
+            (S.opt.quad_kernel == 2 || (S.opt.quad_kernel == 0 && A.cw_entries <= S.opt.oct_max_entries)))
             qshift = 3;
         auto lds_need = [&](int qs, int ss, bool q) {
             const size_t nq = (size_t)1 << qs, nsrc = (size_t)1 << ss, sw = (size_t)(q ? 2 : 1) * A.wtab * nsrc;
@@ -549,10 +556,10 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         };
         for (;;) {
             lds_need(qshift, 0, quad);
-            if (!quad || std::min(lds_stage, S.compact_staging >= 0 ? lds_stage_c : lds_stage) + lds_fixed +
-                                 (size_t)S.lds_pad <= (size_t)S.max_lds)
+            if (!quad || std::min(lds_stage, S.opt.compact_staging >= 0 ? lds_stage_c : lds_stage) + lds_fixed +
+                                 (size_t)S.opt.lds_pad <= (size_t)S.max_lds)
                 break;
-            if (S.quad_kernel > 0)
+            if (S.opt.quad_kernel > 0)
                 return fail(13, "asora_do_all_sources: the multi-sector kernel does not fit in LDS at this radius");
             if (qshift == 3) qshift = 2;
             else { quad = false; qshift = 0; }
@@ -560,18 +567,18 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         // Several consecutive sources of the (curve-sorted) list per workgroup: the smallest radii, whose planes leave
         // most lanes of a wavefront idle and whose tasks are dominated by their set-up.  256 threads, (column density,
         // weight) pairs; automatic while four such workgroups fit on a CU (option "pack_max_lds").
-        if (quad && S.src_pack >= 0 && S.compact_staging <= 0 && (S.wg_threads == 0 || S.wg_threads == 256)) {
+        if (quad && S.opt.src_pack >= 0 && S.opt.compact_staging <= 0 && (S.opt.wg_threads == 0 || S.opt.wg_threads == 256)) {
             // (measured, 1e4 sources at 256^3, unpacked -> four sources per workgroup: R = 3 0.21 -> 0.13 ms, R = 5 0.30 -> 0.27,
             // R = 8 0.76 -> 0.66; R = 10 1.08 -> 1.17: from there on a phase of one source keeps the wavefronts busy and
             // the packed lanes' rate atomics meet in the same cells)
             // eight sources per workgroup pay up to ~32 staged entries (R <= 5: 1e5 sources 2.12 -> 1.87 ms, R = 3 0.175 -> 0.133)
-            for (int ss = (S.src_pack > 0 ? S.src_pack : (A.cw_entries <= 32 ? 3 : 2)); ss >= 2; ss--) {
+            for (int ss = (S.opt.src_pack > 0 ? S.opt.src_pack : (A.cw_entries <= 32 ? 3 : 2)); ss >= 2; ss--) {
                 if (qshift + ss > 6) continue;
                 lds_need(qshift, ss, true);
-                const size_t full = lds_stage + lds_fixed + (size_t)S.lds_pad;
+                const size_t full = lds_stage + lds_fixed + (size_t)S.opt.lds_pad;
                 // (a forced packing that does not fit in LDS degrades to fewer sources per workgroup)
-                if (S.src_pack > 0 ? full <= (size_t)S.max_lds
-                                   : (full <= (size_t)S.pack_max_lds && A.cw_entries <= S.pack_max_entries &&
+                if (S.opt.src_pack > 0 ? full <= (size_t)S.max_lds
+                                   : (full <= (size_t)S.opt.pack_max_lds && A.cw_entries <= S.opt.pack_max_entries &&
                                       num_src >= (8 << ss))) { sshift = ss; break; }
             }
             lds_need(qshift, sshift, true);
@@ -590,7 +597,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     // Measured at 256^3, 1000 sources, updates/s: R = 20: 64 thr 5.4e10, 256 thr 3.2e10; R = 40: 128 thr 9.4e10,
     // 256 thr 8.7e10; R = 60: 256 thr 1.21e11, 512 thr 1.0e11; R = 80: 256 thr 9.4e10, 512 thr 1.26e11;
     // R = 100: 256 thr 5.9e10, global 7.3e10, 1024 thr 1.12e11; R = 120: global 7.2e10, 1024 thr 1.15e11.
-    const int lds_limit = S.lds_stage_limit > 0 ? std::min(S.max_lds, S.lds_stage_limit)
+    const int lds_limit = S.opt.lds_stage_limit > 0 ? std::min(S.max_lds, S.opt.lds_stage_limit)
                                                 : std::max(S.max_lds / 2, std::min(S.max_lds, 65536));
     // Column-density-only staging (8 B per entry, the four weights recomputed per cell: +13 % instructions) once
     // the (column density, weight) pairs would leave room for ONE workgroup per CU or none: two 512-thread
@@ -598,32 +605,32 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     // 1.25e11 updates/s; equal at R = 80), and the LDS range doubles (R = 140: global 7.2e10 -> 1.04e11,
     // R = 160: 7.0e10 -> 9.9e10; 256^3 full box and 512^3 at R = 150 fit).
     bool compact = false;
-    if (use_tab && S.lds_stage_limit <= 0 && S.compact_staging >= 0 && !sshift &&  // (the packed kernels stage pairs)
-        lds_stage_c + lds_fixed + (size_t)S.lds_pad <= (size_t)S.max_lds &&
-        (S.compact_staging > 0 || lds_stage + lds_fixed + (size_t)S.lds_pad > (size_t)S.max_lds / (quad ? 3 : 2) ||
+    if (use_tab && S.opt.lds_stage_limit <= 0 && S.opt.compact_staging >= 0 && !sshift &&  // (the packed kernels stage pairs)
+        lds_stage_c + lds_fixed + (size_t)S.opt.lds_pad <= (size_t)S.max_lds &&
+        (S.opt.compact_staging > 0 || lds_stage + lds_fixed + (size_t)S.opt.lds_pad > (size_t)S.max_lds / (quad ? 3 : 2) ||
          // two workgroups per CU with pairs, four of 256 threads with column densities only: the latter wins while
          // it stays below ~33 KB (R = 73: 79.5 -> 76.1 ms per 4000 sources; equal at R = 76; pairs win from R = 80)
-         (!quad && S.wg_threads == 0 && lds_stage + lds_fixed + (size_t)S.lds_pad > (size_t)S.max_lds / 3 &&
-          lds_stage_c + lds_fixed + (size_t)S.lds_pad <= 33 * 1024))) {
+         (!quad && S.opt.wg_threads == 0 && lds_stage + lds_fixed + (size_t)S.opt.lds_pad > (size_t)S.max_lds / 3 &&
+          lds_stage_c + lds_fixed + (size_t)S.opt.lds_pad <= 33 * 1024))) {
         compact = true;
         lds_stage = lds_stage_c;
     }
-    bool use_lds = lds_stage + lds_fixed + (size_t)S.lds_pad <= (size_t)lds_limit;
+    bool use_lds = lds_stage + lds_fixed + (size_t)S.opt.lds_pad <= (size_t)lds_limit;
     int threads = asora::SWEEP_THREADS;
     if (use_tab) {
-        const size_t full = lds_stage + lds_fixed + (size_t)S.lds_pad;
+        const size_t full = lds_stage + lds_fixed + (size_t)S.opt.lds_pad;
         if (sshift) {  // packed sources: 256 threads, pairs in LDS (checked above)
             threads = 256;
             use_lds = true;
-        } else if (S.wg_threads == 64 || S.wg_threads == 128 || S.wg_threads == 192 || S.wg_threads == 256 ||
-            S.wg_threads == 512 || S.wg_threads == 1024) {
-            threads = S.wg_threads;
+        } else if (S.opt.wg_threads == 64 || S.opt.wg_threads == 128 || S.opt.wg_threads == 192 || S.opt.wg_threads == 256 ||
+            S.opt.wg_threads == 512 || S.opt.wg_threads == 1024) {
+            threads = S.opt.wg_threads;
             if (compact && threads < 256 && !quad) return fail(13, "asora_do_all_sources: compact staging needs wg_threads >= 256");
             if (threads != 256 || compact || quad) {
                 if (full > (size_t)S.max_lds) return fail(13, "asora_do_all_sources: wg_threads=%d needs %zu B of LDS", threads, full);
                 use_lds = true;
             }
-        } else if (S.lds_stage_limit <= 0 && full <= (size_t)S.max_lds) {
+        } else if (S.opt.lds_stage_limit <= 0 && full <= (size_t)S.max_lds) {
             // smallest workgroup that still puts >= 14 of the 16 possible waves on a CU, else the one with the most waves
             static const int sizes[] = {64, 128, 192, 256, 512, 1024};  // (320: measured 30 % slower than 256 / 512)
             const int fit = (int)((size_t)S.max_lds / ((full + 1023) & ~(size_t)1023));
@@ -643,18 +650,18 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             use_lds = true;
         }
     }
-    size_t lds = (use_lds ? lds_stage : 0) + lds_fixed + (size_t)S.lds_pad;
+    size_t lds = (use_lds ? lds_stage : 0) + lds_fixed + (size_t)S.opt.lds_pad;
     // Multi-sector kernels: the lanes of a cell read the same position of 4 / 8 staging arrays, E entries apart.  With
     // E a multiple of 8 (16) the four (eight) reads of a cell fall into the same LDS banks; E = 4 mod 8 (2 mod 4) lets
     // the 16 lanes of one LDS pass tile its banks.  Measured at 1e4 sources: R = 25 (E = 400) 9.12 -> 8.63 ms, R = 30
     // 14.66 -> 14.39 ms; a forced multiple of 32 costs 2 - 6 % at R = 28 ... 45.  The array is padded only while the
     // workgroups per CU stay the same (option "stride_residue": -1 this rule, -2 as the geometry gives it, >= 0: E modulo 32).
     // (Packed sources: 32 - 64 arrays, one per lane of a cell; only a multiple of 16 hurts -- R = 5: 0.273 -> 0.326 ms.)
-    if (use_tab && use_lds && quad && S.stride_residue != -2) {
-        const int mod = S.stride_residue >= 0 ? 32 : (qshift == 3 ? 4 : 8);
-        const int want = S.stride_residue >= 0 ? S.stride_residue % 32 : (qshift == 3 ? 2 : 4);
+    if (use_tab && use_lds && quad && S.opt.stride_residue != -2) {
+        const int mod = S.opt.stride_residue >= 0 ? 32 : (qshift == 3 ? 4 : 8);
+        const int want = S.opt.stride_residue >= 0 ? S.opt.stride_residue % 32 : (qshift == 3 ? 2 : 4);
         int delta = ((want - A.cw_entries) % mod + mod) % mod;
-        if (sshift && S.stride_residue < 0) delta = A.cw_entries % 16 == 0 ? 1 : 0;
+        if (sshift && S.opt.stride_residue < 0) delta = A.cw_entries % 16 == 0 ? 1 : 0;
         const size_t lds2 = lds + (size_t)delta * ((size_t)1 << (qshift + sshift)) * (compact ? 8 : 16);
         auto per_cu = [&](size_t b) { return (size_t)S.max_lds / ((b + 1023) & ~(size_t)1023); };
         if (delta && lds2 <= (size_t)S.max_lds && per_cu(lds2) == per_cu(lds)) {
@@ -681,13 +688,13 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             }
             A.gscratch = S.gscratch;
         }
-        S.last_tab = use_tab ? 1 : 0;
+        S.rec.last_tab = use_tab ? 1 : 0;
         HIP_TRY(hipEventRecord(S.ev0, st));
         if (use_tab) {
             constexpr int T = asora::SWEEP_THREADS;
             // ("skip_saturated": the LDS-staged single-sector kernels of 256 / 512 / 1024 threads have a variant with the test
             // compiled in -- the radii at which a source's light can saturate the table; the others ignore the option)
-            const bool sat = S.skip_saturated && !quad && use_lds && threads >= 256;
+            const bool sat = S.opt.skip_saturated && !quad && use_lds && threads >= 256;
 #define ASORA_LAUNCH_TAB(L, TH, WS) \
     (sat && L && TH >= 256 ? ASORA_LAUNCH_SAT(TH, WS) : ASORA_LAUNCH_PLAIN(L, TH, WS))
 #define ASORA_LAUNCH_PLAIN(L, TH, WS) \
@@ -739,8 +746,8 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         if (rc) return rc;
         HIP_TRY(hipEventRecord(S.ev1, st));
         S.timed = true;
-        S.last_grid = grid; S.last_block = use_tab ? threads : asora::SWEEP_THREADS; S.last_lds = (int)lds;
-        S.last_is_lds = (use_lds ? (compact ? 2 : 1) : 0) | (qshift << 2) | (sshift << 4);
+        S.rec.last_grid = grid; S.rec.last_block = use_tab ? threads : asora::SWEEP_THREADS; S.rec.last_lds = (int)lds;
+        S.rec.last_is_lds = (use_lds ? (compact ? 2 : 1) : 0) | (qshift << 2) | (sshift << 4);
     }
 
     hipLaunchKernelGGL(asora::finalize_kernel, tg, tb, 0, st, S.phiA, S.phiB, phi_out_dev, N);
@@ -963,9 +970,8 @@ int asora_device_close(void) {
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     State fresh;  // options and the last launch record survive a close
-    fresh.force_generic = S.force_generic; fresh.lds_pad = S.lds_pad; fresh.lds_stage_limit = S.lds_stage_limit; fresh.wg_threads = S.wg_threads; fresh.source_order = S.source_order; fresh.skip_unobserved = S.skip_unobserved; fresh.skip_saturated = S.skip_saturated; fresh.compact_staging = S.compact_staging; fresh.quad_kernel = S.quad_kernel; fresh.quad_max_entries = S.quad_max_entries; fresh.oct_max_entries = S.oct_max_entries; fresh.stride_residue = S.stride_residue; fresh.last_quad = S.last_quad; fresh.src_pack = S.src_pack; fresh.pack_max_lds = S.pack_max_lds; fresh.pack_max_entries = S.pack_max_entries; fresh.max_table_cells = S.max_table_cells;
-    fresh.last_tab = S.last_tab; fresh.last_grid = S.last_grid; fresh.last_block = S.last_block;
-    fresh.last_lds = S.last_lds; fresh.last_is_lds = S.last_is_lds;
+    fresh.opt = S.opt;
+    fresh.rec = S.rec;
     const int dev = S.device;
     S = fresh;
     S.device = dev;  // (the guard above still restores the caller's device)
@@ -1266,28 +1272,28 @@ int asora_last_sweep_ms(float *ms) {
 
 int asora_set_option(const char *name, long long value) {
     if (!name) return fail(9, "asora_set_option: null name");
-    if (!std::strcmp(name, "force_generic")) S.force_generic = value != 0;
-    else if (!std::strcmp(name, "max_table_cells")) S.max_table_cells = value;
-    else if (!std::strcmp(name, "lds_pad")) S.lds_pad = (int)value;
-    else if (!std::strcmp(name, "lds_stage_limit")) S.lds_stage_limit = (int)value;
-    else if (!std::strcmp(name, "wg_threads")) S.wg_threads = (int)value;
-    else if (!std::strcmp(name, "source_order")) S.source_order = (int)value;
-    else if (!std::strcmp(name, "quad_kernel")) S.quad_kernel = (int)value;
-    else if (!std::strcmp(name, "quad_max_entries")) S.quad_max_entries = (int)value;
-    else if (!std::strcmp(name, "oct_max_entries")) S.oct_max_entries = (int)value;
-    else if (!std::strcmp(name, "stride_residue")) S.stride_residue = (int)value;
-    else if (!std::strcmp(name, "compact_staging")) S.compact_staging = (int)value;
-    else if (!std::strcmp(name, "src_pack")) S.src_pack = (int)value;
-    else if (!std::strcmp(name, "pack_max_lds")) S.pack_max_lds = (int)value;
-    else if (!std::strcmp(name, "pack_max_entries")) S.pack_max_entries = (int)value;
-    else if (!std::strcmp(name, "skip_unobserved")) S.skip_unobserved = value != 0;
-    else if (!std::strcmp(name, "skip_saturated")) S.skip_saturated = value != 0;
+    if (!std::strcmp(name, "force_generic")) S.opt.force_generic = value != 0;
+    else if (!std::strcmp(name, "max_table_cells")) S.opt.max_table_cells = value;
+    else if (!std::strcmp(name, "lds_pad")) S.opt.lds_pad = (int)value;
+    else if (!std::strcmp(name, "lds_stage_limit")) S.opt.lds_stage_limit = (int)value;
+    else if (!std::strcmp(name, "wg_threads")) S.opt.wg_threads = (int)value;
+    else if (!std::strcmp(name, "source_order")) S.opt.source_order = (int)value;
+    else if (!std::strcmp(name, "quad_kernel")) S.opt.quad_kernel = (int)value;
+    else if (!std::strcmp(name, "quad_max_entries")) S.opt.quad_max_entries = (int)value;
+    else if (!std::strcmp(name, "oct_max_entries")) S.opt.oct_max_entries = (int)value;
+    else if (!std::strcmp(name, "stride_residue")) S.opt.stride_residue = (int)value;
+    else if (!std::strcmp(name, "compact_staging")) S.opt.compact_staging = (int)value;
+    else if (!std::strcmp(name, "src_pack")) S.opt.src_pack = (int)value;
+    else if (!std::strcmp(name, "pack_max_lds")) S.opt.pack_max_lds = (int)value;
+    else if (!std::strcmp(name, "pack_max_entries")) S.opt.pack_max_entries = (int)value;
+    else if (!std::strcmp(name, "skip_unobserved")) S.opt.skip_unobserved = value != 0;
+    else if (!std::strcmp(name, "skip_saturated")) S.opt.skip_saturated = value != 0;
     else if (!std::strcmp(name, "copy_threads")) g_copy_threads = (int)std::max<long long>(0, std::min<long long>(value, Stager::MAXT));
     else return fail(12, "asora_set_option: unknown option '%s'", name);
     return 0;
 }
 
-int asora_last_sweep_is_table_driven(void) { return S.last_tab; }
+int asora_last_sweep_is_table_driven(void) { return S.rec.last_tab; }
 
 int asora_test_division(const double *num, const double *den, long long n, long long *mismatch_div,
                         long long *mismatch_rcp, long long *mismatch_const) {
@@ -1312,10 +1318,10 @@ int asora_test_division(const double *num, const double *den, long long n, long 
 }
 
 int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_is_lds) {
-    if (grid) *grid = S.last_grid;
-    if (block) *block = S.last_block;
-    if (lds_bytes) *lds_bytes = S.last_lds;
-    if (staging_is_lds) *staging_is_lds = S.last_is_lds;
+    if (grid) *grid = S.rec.last_grid;
+    if (block) *block = S.rec.last_block;
+    if (lds_bytes) *lds_bytes = S.rec.last_lds;
+    if (staging_is_lds) *staging_is_lds = S.rec.last_is_lds;
     return 0;
 }
 
