@@ -1299,11 +1299,15 @@ int asora_test_division(const double *num, const double *den, long long n, long 
                         long long *mismatch_rcp, long long *mismatch_const) {
     if (!num || !den || n < 1 || !mismatch_div || !mismatch_rcp || !mismatch_const)
         return fail(9, "asora_test_division: bad arguments");
-    double *d_n = nullptr, *d_d = nullptr;
-    unsigned long long *d_c = nullptr;
-    HIP_TRY(hipMalloc(&d_n, n * sizeof(double)));
-    HIP_TRY(hipMalloc(&d_d, n * sizeof(double)));
-    HIP_TRY(hipMalloc(&d_c, 3 * sizeof(unsigned long long)));
+    struct Scoped {  // device buffers of this call: freed on every return path
+        void *p = nullptr;
+        ~Scoped() { if (p) (void)hipFree(p); }
+    } b_n, b_d, b_c;
+    HIP_TRY(hipMalloc(&b_n.p, n * sizeof(double)));
+    HIP_TRY(hipMalloc(&b_d.p, n * sizeof(double)));
+    HIP_TRY(hipMalloc(&b_c.p, 3 * sizeof(unsigned long long)));
+    double *d_n = static_cast<double *>(b_n.p), *d_d = static_cast<double *>(b_d.p);
+    unsigned long long *d_c = static_cast<unsigned long long *>(b_c.p);
     HIP_TRY(hipMemcpy(d_n, num, n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_d, den, n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(d_c, 0, 3 * sizeof(unsigned long long)));
@@ -1312,7 +1316,6 @@ int asora_test_division(const double *num, const double *den, long long n, long 
     HIP_TRY(hipGetLastError());
     unsigned long long c[3];
     HIP_TRY(hipMemcpy(c, d_c, sizeof c, hipMemcpyDeviceToHost));
-    (void)hipFree(d_n); (void)hipFree(d_d); (void)hipFree(d_c);
     *mismatch_div = (long long)c[0]; *mismatch_rcp = (long long)c[1]; *mismatch_const = (long long)c[2];
     return 0;
 }
