@@ -7,9 +7,9 @@ fraction has converged, then return ``(xh_new, phi_ion, coldensh_out)``.
 What is kept from the reference: the argument list, the flattening (C-order ``ravel`` +
 ``astype(float64)``, ``:171-172``), the source wire format and contiguous sharding (``:173-189``), one
 upload of sources and density per step (``:192,201``), the convergence criterion
-``conv_criterion = min(int(convergence_fraction*N^3), (NumSrc-1)/3)`` (``:154``, with NumSrc the
-rank-local count exactly like the reference, ``:183``) and the two relative-change tests
-(``:350-373``).
+``conv_criterion = min(int(convergence_fraction*N^3), (NumSrc-1)/3)`` (``:154``) -- formed from the
+**global** source count of ``:147``: the reference overwrites ``NumSrc`` with the shard size only
+afterwards, at ``:183`` -- and the two relative-change tests (``:350-373``).
 
 What is different (MI355X-first): all grids stay on the device for the whole step.  The raytrace
 writes phi_ion into a device tensor, the rank sum is ONE in-place RCCL all-reduce of that tensor
@@ -20,8 +20,11 @@ iteration 24 bytes cross PCIe.  Every rank runs the (deterministic, per-cell) ch
 identical inputs; the convergence decision is taken on rank 0 and broadcast, so ranks cannot diverge
 on it.
 
-``_evolve_loop`` is the host logic with the two device operations injected; the tests drive it
-with the CPU oracle to pin the loop itself (tests/test_evolve_host.py).
+``_evolve_loop`` is the iteration with the two device operations injected; ``_sharded_step`` is the
+whole host logic of a step (criterion from the global list, shard, upload, loop, collective decision)
+with every device operation injected.  ``evolve3D`` runs it on the HIP library; the tests run the very
+same function on the CPU oracle, single rank and world-2 gloo (tests/test_evolve_host.py,
+tests/test_distributed_cpu.py).
 """
 from __future__ import annotations
 
@@ -33,7 +36,7 @@ __all__ = ["evolve3D", "conv_criterion"]
 
 
 def conv_criterion(convergence_fraction, num_cells, num_src):
-    """evolve.py:154"""
+    """evolve.py:154 -- ``num_src`` is the length of the whole source list (``:147``), on every rank."""
     return min(int(convergence_fraction * num_cells), (num_src - 1) / 3)
 
 
@@ -42,9 +45,9 @@ def _evolve_loop(raytrace, chemistry, num_cells, num_src, convergence_fraction, 
     """The ``while not converged`` loop of evolve.py:232-401.
 
     ``raytrace()`` must leave the all-rank phi_ion where ``chemistry`` finds it; ``chemistry()``
-    returns ``(conv_flag, sum(xh_intermed), sum(1 - xh_intermed))``.  ``decide(bool) -> bool`` makes the
-    decision collective (rank 0's value wins); identity for a single process.  Returns the number of
-    iterations."""
+    returns ``(conv_flag, sum(xh_intermed), sum(1 - xh_intermed))``.  ``num_src`` is the GLOBAL number of
+    sources (see ``conv_criterion``).  ``decide(bool) -> bool`` makes the decision collective (rank 0's
+    value wins); identity for a single process.  Returns the number of iterations."""
     crit = conv_criterion(convergence_fraction, num_cells, num_src)
     prev_sum_xh1_int = 2 * num_cells
     prev_sum_xh0_int = 2 * num_cells
@@ -68,12 +71,56 @@ def _evolve_loop(raytrace, chemistry, num_cells, num_src, convergence_fraction, 
             converged = decide(converged)
         if history is not None:
             history.append(dict(conv_flag=int(conv_flag), rel_change_xh1=float(rel_change_xh1),
-                                rel_change_xh0=float(rel_change_xh0)))
+                                rel_change_xh0=float(rel_change_xh0), conv_criterion=float(crit)))
         prev_sum_xh1_int = sum_xh1_int
         prev_sum_xh0_int = sum_xh0_int
         if niter >= max_iter:
             raise RuntimeError(f"evolve3D: no convergence after {niter} iterations")
     return niter
+
+
+def _process_group():
+    """(rank, nprocs, distributed) of ``torch.distributed``'s default group; (0, 1, False) without one."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.get_rank(), dist.get_world_size(), True
+    return 0, 1, False
+
+
+def _sharded_step(src_flux, src_pos, num_cells, convergence_fraction, upload_sources, raytrace_local, rate_grid,
+                  chemistry, device="cpu", history=None):
+    """Host logic of one evolve step on this rank (evolve.py:146-192, 232-401).
+
+    ``src_flux`` (Ns,), ``src_pos`` (3, Ns): the WHOLE list, identical on every rank.
+    ``upload_sources(pos_flat, flux_flat, n_local)`` gets this rank's contiguous shard once;
+    ``raytrace_local()`` overwrites ``rate_grid`` (a torch tensor on ``device``) with the shard's rates;
+    the grid is then summed over the ranks in place; ``chemistry()`` as in ``_evolve_loop``.
+    Returns ``(niter, n_local)``."""
+    import torch
+    import torch.distributed as dist
+    rank, nprocs, distributed = _process_group()
+    src_flux = np.asarray(src_flux)
+    src_pos = np.asarray(src_pos)
+    num_src_global = src_flux.shape[0]          # evolve.py:147 -- the criterion of :154 is formed from this
+    lo, hi = shard_sources(num_src_global, rank, nprocs)
+    n_local = hi - lo                           # evolve.py:183
+    upload_sources(*format_sources(src_pos[:, lo:hi], src_flux[lo:hi]), n_local)
+
+    def raytrace():
+        raytrace_local()
+        if distributed:
+            dist.all_reduce(rate_grid)          # replaces Reduce + Bcast, evolve.py:309-317
+
+    def decide(flag):
+        if not distributed:
+            return flag
+        t = torch.tensor([int(flag)], dtype=torch.int32, device=device)
+        dist.broadcast(t, src=0)                # evolve.py:398
+        return bool(t.item())
+
+    niter = _evolve_loop(raytrace, chemistry, num_cells, num_src_global, convergence_fraction, decide,
+                         history=history)
+    return niter, n_local
 
 
 def evolve3D(dt, dr, src_flux, src_pos, use_gpu, max_subbox, subboxsize, loss_fraction, use_mpi, comm, rank,
@@ -86,7 +133,6 @@ def evolve3D(dt, dr, src_flux, src_pos, use_gpu, max_subbox, subboxsize, loss_fr
 
     Returns ``(xh_new, phi_ion, coldensh_out)`` as (N, N, N) float64 numpy arrays."""
     import torch
-    import torch.distributed as dist
 
     from . import asora_core
     libasora = asora_core.libasora
@@ -94,18 +140,10 @@ def evolve3D(dt, dr, src_flux, src_pos, use_gpu, max_subbox, subboxsize, loss_fr
         raise NotImplementedError("pyc2ray_amd implements the ASORA (GPU) branch of evolve3D only")
     if not asora_core.cuda_is_init():
         raise RuntimeError("GPU not initialized. Please initialize it by calling device_init(N)")
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    rank, nprocs = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
 
-    src_flux = np.asarray(src_flux)
-    src_pos = np.asarray(src_pos)
     N = temp.shape[0]
     NumCells = N * N * N
     NumTau = photo_thin_table.shape[0]
-    lo, hi = shard_sources(src_flux.shape[0], rank, nprocs)
-    NumSrc = hi - lo
-    srcpos_flat, normflux_flat = format_sources(src_pos[:, lo:hi], src_flux[lo:hi])
-    libasora.source_data_to_device(srcpos_flat, normflux_flat, NumSrc)
 
     # the library's grids live on the device device_init selected: the step's tensors must live there too
     dev = torch.device("cuda", libasora.device_index())
@@ -117,26 +155,27 @@ def evolve3D(dt, dr, src_flux, src_pos, use_gpu, max_subbox, subboxsize, loss_fr
     cdh_t = torch.zeros(NumCells, dtype=torch.float64, device=dev) if want_coldens else None
     stream = torch.cuda.current_stream(dev).cuda_stream
     libasora.density_from_device(ndens_t.data_ptr(), N, stream)
+    local = {}
 
-    def raytrace():
+    def upload_sources(pos_flat, flux_flat, n_local):
+        local["n"] = n_local
+        if n_local:
+            libasora.source_data_to_device(pos_flat, flux_flat, n_local)
+
+    def raytrace_local():
+        if local["n"] == 0:        # more ranks than sources: this rank adds nothing to the sum
+            phi_t.zero_()
+            return
         libasora.do_all_sources_dev(R_max_LLS, cdh_t.data_ptr() if want_coldens else 0, sig, dr, xh_av_t.data_ptr(),
-                                    phi_t.data_ptr(), 0, NumSrc, N, minlogtau, dlogtau, NumTau, stream)
-        if distributed:
-            dist.all_reduce(phi_t)
+                                    phi_t.data_ptr(), 0, local["n"], N, minlogtau, dlogtau, NumTau, stream)
 
     def chemistry():
         return libasora.global_pass_dev(dt, ndens_t.data_ptr(), temp_t.data_ptr(), xh_t.data_ptr(),
                                         xh_av_t.data_ptr(), xh_intermed_t.data_ptr(), phi_t.data_ptr(),
                                         clump_t.data_ptr(), bh00, albpow, colh0, temph0, abu_c, N, stream)
 
-    def decide(flag):
-        if not distributed:
-            return flag
-        t = torch.tensor([int(flag)], dtype=torch.int32, device=dev)
-        dist.broadcast(t, src=0)
-        return bool(t.item())
-
-    _evolve_loop(raytrace, chemistry, NumCells, NumSrc, convergence_fraction, decide, history=history)
+    _sharded_step(src_flux, src_pos, NumCells, convergence_fraction, upload_sources, raytrace_local, phi_t,
+                  chemistry, device=dev, history=history)
     shape = (N, N, N)
     xh_new = xh_intermed_t.cpu().numpy().reshape(shape)
     phi_ion = phi_t.cpu().numpy().reshape(shape)

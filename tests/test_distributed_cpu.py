@@ -62,6 +62,82 @@ def test_shard_and_allreduce_world2(tmp_path, port_oracle):
     assert np.array_equal(p0 != 0, m)
 
 
+def _evolve_rank_main(rank, world, port, out_dir, case_name):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from evolve_host import evolve3D_host_sharded
+    from oracle.oracle import PortOracle
+    r = evolve3D_host_sharded(PortOracle(), _EVOLVE_CASES[case_name]())
+    np.savez(os.path.join(out_dir, f"evolve_{rank}.npz"), xh_new=r["xh_new"], phi_ion=r["phi_ion"], niter=r["niter"],
+             conv_flags=np.array(r["conv_flags"]), n_local=r["n_local"], conv_criterion=r["conv_criterion"])
+    dist.destroy_process_group()
+
+
+def _evolve_case10():
+    """10 sources in a 16^3 box with convergence_fraction 1e-3: int(1e-3 * 4096) = 4 > (10 - 1) / 3 = 3.0, so the
+    source-count term of the criterion binds (pyc2ray/evolve.py:154).  Formed per shard it would be 0.33 (two
+    sources on ranks 0-2) and 1.0 (four on rank 3)."""
+    import cases
+    c = cases.evolve_case(N=16, seed=9)
+    rng = np.random.default_rng(77)
+    c["pos"] = rng.integers(0, 16, (10, 3)).astype(np.int32)
+    c["flux"] = rng.uniform(0.05, 2.0, 10)
+    c["convergence_fraction"] = 1e-3
+    return c
+
+
+def _evolve_case32():
+    import cases
+    return cases.evolve_case()
+
+
+_EVOLVE_CASES = {"evolve32": _evolve_case32, "ten_sources16": _evolve_case10}
+
+
+@pytest.mark.timeout(600)
+def test_evolve_step_world2_equals_single_rank_golden(tmp_path, golden_dir):
+    """The evolve32 step with its three sources sharded 1 + 2 over two gloo ranks, every device operation done by
+    the port oracle, the host logic being the product's (_sharded_step): both ranks return the same grids, and
+    iteration count, per-iteration conv_flag and xHII are those of the single-rank golden (made from the compiled
+    reference).  With the criterion formed from the shard sizes (0 on rank 0, whose decision is broadcast) the
+    loop would run on until the relative-change test ends it."""
+    world = 2
+    mp.spawn(_evolve_rank_main, args=(world, _free_port(), str(tmp_path), "evolve32"), nprocs=world, join=True)
+    g = np.load(os.path.join(golden_dir, "evolve32.npz"))
+    r0, r1 = (np.load(tmp_path / f"evolve_{r}.npz") for r in range(world))
+    assert [int(r0["n_local"]), int(r1["n_local"])] == [1, 2]
+    assert np.array_equal(r0["xh_new"], r1["xh_new"]) and np.array_equal(r0["phi_ion"], r1["phi_ion"])
+    assert float(r0["conv_criterion"]) == float(r1["conv_criterion"]) == (3 - 1) / 3
+    assert int(r0["niter"]) == int(r1["niter"]) == int(g["niter"])
+    assert list(r0["conv_flags"]) == list(g["conv_flags"])
+    assert np.max(np.abs(r0["xh_new"] - g["xh_new"])) <= 1e-12
+    m = g["phi_ion"] > 0
+    assert np.max(np.abs(r0["phi_ion"][m] / g["phi_ion"][m] - 1.0)) <= 1e-10
+
+
+@pytest.mark.timeout(600)
+def test_evolve_step_world4_criterion_is_global(tmp_path, port_oracle):
+    """10 sources on 4 ranks (shards 2, 2, 2, 4): every rank forms the reference's criterion 3.0 from the global
+    list and the loop iterates exactly like the single-rank run."""
+    from evolve_host import evolve3D_host_sharded
+    world = 4
+    mp.spawn(_evolve_rank_main, args=(world, _free_port(), str(tmp_path), "ten_sources16"), nprocs=world, join=True)
+    one = evolve3D_host_sharded(port_oracle, _evolve_case10())      # no process group here: single rank
+    assert one["conv_criterion"] == 3.0 and one["n_local"] == 10
+    rs = [np.load(tmp_path / f"evolve_{r}.npz") for r in range(world)]
+    assert [int(r["n_local"]) for r in rs] == [2, 2, 2, 4]
+    for r in rs:
+        assert float(r["conv_criterion"]) == 3.0
+        assert int(r["niter"]) == one["niter"] and list(r["conv_flags"]) == one["conv_flags"]
+        assert np.array_equal(r["xh_new"], rs[0]["xh_new"])
+        assert np.max(np.abs(r["xh_new"] - one["xh_new"])) <= 1e-12
+    # the case does discriminate: the loop ends on a conv_flag between the per-shard criteria (0.33 on rank 0,
+    # whose decision is broadcast) and the global one
+    assert 1 <= one["conv_flags"][-1] < 3
+
+
 def _bench(*args, env=None):
     import subprocess
     e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}

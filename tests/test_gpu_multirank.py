@@ -1,4 +1,4 @@
-"""The N > 1 path of bench.py on the GPU: two ranks (one GPU here, so the all-reduce goes through gloo and
+"""The N > 1 paths on the GPU -- evolve3D and bench.py: two ranks (one GPU here, so the all-reduce goes through gloo and
 the host -- ASORA_BENCH_BACKEND=gloo; RCCL refuses two ranks on one device) shard the source list and
 must reproduce the single-rank rate grid."""
 import json
@@ -69,3 +69,50 @@ def test_rccl_allreduce_follows_the_sweep_on_its_stream():
     assert b["per_rank"]["allreduce_ms"][0] > 0.0
     ca, cb = a["config"]["phi_checksum"], b["config"]["phi_checksum"]
     assert ca > 0 and abs(ca - cb) <= 1e-12 * ca, (ca, cb)
+
+
+def _run_evolve_ranks(world, out_dir, case_name):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "tests", "evolve_rank_worker.py"), str(out_dir), case_name],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import numpy as np
+    return [np.load(os.path.join(out_dir, f"evolve_{k}.npz")) for k in range(world)]
+
+
+@pytest.mark.gpu
+def test_evolve3D_two_ranks_equal_the_single_rank_golden(tmp_path):
+    """pyc2ray_amd.evolve.evolve3D with world_size 2 (reference: pyc2ray/evolve.py:147-154, 173-187, 309-317,
+    386-398): the three sources of the evolve32 case sharded 1 + 2 over two fresh processes on the one GPU.  Both
+    ranks must return identical grids; iteration count and per-iteration conv_flag must be those of the
+    single-rank golden made from the compiled reference (the criterion comes from the GLOBAL source count), xHII
+    within north_star's 1e-8."""
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "evolve32.npz"))
+    r0, r1 = _run_evolve_ranks(2, tmp_path, "evolve32")
+    assert np.array_equal(r0["xh_new"], r1["xh_new"]) and np.array_equal(r0["phi_ion"], r1["phi_ion"])
+    assert float(r0["conv_criterion"]) == float(r1["conv_criterion"]) == (3 - 1) / 3
+    assert int(r0["niter"]) == int(r1["niter"]) == int(g["niter"])
+    assert list(r0["conv_flags"]) == list(r1["conv_flags"]) == list(g["conv_flags"])
+    err = np.max(np.abs(r0["xh_new"] - g["xh_new"]))
+    print(f"[evolve32, 2 ranks] niter {int(r0['niter'])}  max|d xHII| {err:.2e}")
+    assert err <= 1e-8
+    m = g["phi_ion"] > 0
+    assert np.max(np.abs(r0["phi_ion"][m] / g["phi_ion"][m] - 1.0)) <= 1e-8
+
+
+@pytest.mark.gpu
+def test_evolve3D_four_ranks_ten_sources(tmp_path):
+    """10 sources on 4 ranks (2, 2, 2, 4): the criterion is the reference's 3.0 on every rank and the loop ends
+    where the single-rank run ends."""
+    import numpy as np
+    one = _run_evolve_ranks(1, tmp_path / "one", "ten_sources16") if (tmp_path / "one").mkdir() is None else None
+    rs = _run_evolve_ranks(4, tmp_path, "ten_sources16")
+    for r in rs:
+        assert float(r["conv_criterion"]) == 3.0
+        assert int(r["niter"]) == int(one[0]["niter"]) and list(r["conv_flags"]) == list(one[0]["conv_flags"])
+        assert np.array_equal(r["xh_new"], rs[0]["xh_new"])
+        assert np.max(np.abs(r["xh_new"] - one[0]["xh_new"])) <= 1e-8
+    assert 1 <= int(one[0]["conv_flags"][-1]) < 3
