@@ -42,6 +42,18 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Test-only variant (oracle/Makefile `port_devlog10`, -DORACLE_LOG10_DEVICE): the lookup's log10 is the host build
+ * of the HIP kernels' table-driven log10 (oracle/log10_device.cpp) instead of glibc's.  Nothing else changes.  It
+ * isolates libm-to-libm variation of log10 as the cause of the cells tests/parity.py's conditioning term admits. */
+#ifdef ORACLE_LOG10_DEVICE
+double c2ray_log10_device(double x);
+#define LOOKUP_LOG10(x) c2ray_log10_device(x)
+int c2ray_oracle_log10_kind(void) { return 1; }
+#else
+#define LOOKUP_LOG10(x) log10(x)
+int c2ray_oracle_log10_kind(void) { return 0; }
+#endif
+
 #define IDX(i, j, k, m2, m3) (((size_t)(i) * (size_t)(m2) + (size_t)(j)) * (size_t)(m3) + (size_t)(k))
 
 static const double PI_D = 3.14159265358979323846264338; /* raytracing.f90:47 */
@@ -62,7 +74,7 @@ static inline int i_max(int a, int b) { return a > b ? a : b; }
  * ---------------------------------------------------------------------------------------- */
 static double photo_lookuptable(double tau, const double *table, double minlogtau, double dlogtau,
                                 int NumTau) {
-    double logtau = log10(fmax(1.0e-20, tau));
+    double logtau = LOOKUP_LOG10(fmax(1.0e-20, tau));
     /* real(NumTau) is default real */
     double real_i = fmin((double)(float)NumTau, fmax(0.0, 1.0 + (logtau - minlogtau) / dlogtau));
     int i0 = (int)real_i;
@@ -78,7 +90,7 @@ static double photo_lookuptable(double tau, const double *table, double minlogta
  * correct implementations with different libm's may legitimately differ in that cell. */
 static double photo_lookuptable_shift(double tau, const double *table, double minlogtau, double dlogtau,
                                       int NumTau, int shift) {
-    double logtau = log10(fmax(1.0e-20, tau));
+    double logtau = LOOKUP_LOG10(fmax(1.0e-20, tau));
     for (int s = 0; s < (shift < 0 ? -shift : shift); s++) logtau = nextafter(logtau, shift < 0 ? -INFINITY : INFINITY);
     double real_i = fmin((double)(float)NumTau, fmax(0.0, 1.0 + (logtau - minlogtau) / dlogtau));
     int i0 = (int)real_i;

@@ -3,6 +3,9 @@
 Two back ends with one calling convention:
 
 * ``port``  -- oracle/libc2ray_oracle.so, our own C restatement (oracle/c2ray_oracle.c);
+* ``port`` with ``log10="device"`` -- oracle/libc2ray_oracle_devlog10.so: the same restatement with ONE change,
+  the table lookup's log10 is the host build of the HIP kernels' table-driven log10 (oracle/log10_device.cpp).
+  It is the checker of the conditioning argument of tests/parity.py, never the parity reference;
 * ``ref``   -- oracle/_ref/libc2ray_ref.so, the reference Fortran compiled by ``make -C oracle ref``
   in the build container (flang name mangling ``_QM<module>P<proc>``, every scalar by
   reference, trailing hidden sizes as in src/c2ray/raytracing.f90:52-56).
@@ -23,6 +26,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PORT_SO = os.path.join(HERE, "libc2ray_oracle.so")
+DEVLOG_SO = os.path.join(HERE, "libc2ray_oracle_devlog10.so")
 REF_SO = os.path.join(HERE, "_ref", "libc2ray_ref.so")
 
 _dp = C.POINTER(C.c_double)
@@ -34,6 +38,14 @@ def build_port(force: bool = False) -> str:
     if force or not os.path.exists(PORT_SO) or os.path.getmtime(PORT_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", HERE, "port"], stdout=subprocess.DEVNULL)
     return PORT_SO
+
+
+def build_port_devlog10(force: bool = False) -> str:
+    deps = [os.path.join(HERE, "c2ray_oracle.c"), os.path.join(HERE, "log10_device.cpp"),
+            os.path.join(HERE, "..", "pyc2ray_amd", "csrc", "asora_log10.hpp")]
+    if force or not os.path.exists(DEVLOG_SO) or any(os.path.getmtime(DEVLOG_SO) < os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["make", "-C", HERE, "port_devlog10"], stdout=subprocess.DEVNULL)
+    return DEVLOG_SO
 
 
 def build_ref(reference: str = "/root/reference") -> str | None:
@@ -53,9 +65,15 @@ class PortOracle:
 
     kind = "port"
 
-    def __init__(self):
-        self.lib = C.CDLL(build_port())
+    def __init__(self, log10: str = "libm"):
+        """log10="device": the variant whose lookups use the HIP kernels' log10 (see the module docstring)."""
+        if log10 not in ("libm", "device"):
+            raise ValueError(log10)
+        self.lib = C.CDLL(build_port() if log10 == "libm" else build_port_devlog10())
+        self.log10 = log10
         L = self.lib
+        L.c2ray_oracle_log10_kind.restype = C.c_int
+        assert L.c2ray_oracle_log10_kind() == (1 if log10 == "device" else 0)
         L.c2ray_do_all_sources.restype = C.c_longlong
         L.c2ray_do_all_sources.argtypes = [
             _dp, _ip, C.c_int, C.c_int, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _dp, _ip, _dp, C.c_float,

@@ -20,6 +20,13 @@ def port_oracle():
 
 
 @pytest.fixture(scope="session")
+def devlog_oracle():
+    """The port with the HIP kernels' table-driven log10 in its lookups: checker of the conditioning argument."""
+    from oracle.oracle import PortOracle
+    return PortOracle(log10="device")
+
+
+@pytest.fixture(scope="session")
 def ref_oracle():
     """The compiled reference Fortran (oracle/_ref/libc2ray_ref.so: built in the container, travels to the GPU
     box as a built file), or None where it was never built."""

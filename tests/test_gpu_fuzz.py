@@ -16,6 +16,8 @@ def asora():
     from pyc2ray_amd import libasora
     return libasora
 
+FUZZ_STATS = dict(n=0, n_sens_vs_glibc_oracle=0, max_rel_vs_device_log10_oracle=0.0, frac_floor_max=0.0)
+
 MESHES = [4, 5, 7, 8, 12, 17, 24, 31, 40]
 VARIANTS = [dict(), dict(wg_threads=64), dict(wg_threads=128), dict(wg_threads=192), dict(wg_threads=512),
             dict(wg_threads=1024), dict(wg_threads=1024, compact_staging=1), dict(wg_threads=256, compact_staging=1),
@@ -29,7 +31,7 @@ VARIANTS = [dict(), dict(wg_threads=64), dict(wg_threads=128), dict(wg_threads=1
 
 
 @pytest.mark.parametrize("seed", range(156))
-def test_random_small_case_vs_oracle(asora, port_oracle, seed):
+def test_random_small_case_vs_oracle(asora, port_oracle, devlog_oracle, seed):
     rng = np.random.default_rng(9000 + seed)
     N = MESHES[seed % len(MESHES)]
     R = [0.4, 1.0, 1.7, 2.5, N / 3.0, N / 2.0 + 0.3, float(N), 3.0 * N][int(rng.integers(0, 8))]
@@ -55,8 +57,31 @@ def test_random_small_case_vs_oracle(asora, port_oracle, seed):
     if with_heat:
         rh = compare(heat, o["phi_heat"], sens=o["heat_sens"])
         assert rh["ok"], (N, R, ns, opts, rh)
+    # ... and against the oracle with the device's log10 the plain bar holds with no conditioning term
+    # (tests/test_gpu_parity.py::test_phi_vs_device_log10_oracle)
+    od = cases.run_oracle(devlog_oracle, c, heat=with_heat)
+    rd = compare(phi, od["phi_ion"])
+    assert rd["ok"] and rd["support_equal"], (N, R, ns, opts, rd)
+    FUZZ_STATS["n"] += 1
+    FUZZ_STATS["n_sens_vs_glibc_oracle"] += r["n_sens"]
+    FUZZ_STATS["max_rel_vs_device_log10_oracle"] = max(FUZZ_STATS["max_rel_vs_device_log10_oracle"], rd["max_rel"])
+    FUZZ_STATS["frac_floor_max"] = max(FUZZ_STATS["frac_floor_max"], rd["frac_floor"])
+    if with_heat:
+        rdh = compare(heat, od["phi_heat"])
+        assert rdh["ok"], (N, R, ns, opts, rdh)
     # column density of the last source: bit-identical wherever both swept
     last = dict(c, pos=c["pos"][-1:], flux=c["flux"][-1:])
     ol = cases.run_oracle(port_oracle, last, heat=False)
     m = (cdh != 0) & (ol["coldensh_out"] != 0)
     assert np.array_equal(cdh[m], ol["coldensh_out"][m]), (N, R, ns, opts)
+
+
+def test_zz_fuzz_summary_to_parity_report():
+    """One line for the parity report: all fuzz cases against the device-log10 oracle at the plain bar."""
+    from parity import record
+    if FUZZ_STATS["n"] == 0:
+        pytest.skip("fuzz cases did not run in this process")
+    record(f"fuzz: {FUZZ_STATS['n']} seeded cases vs device-log10 oracle (no conditioning term)",
+           dict(max_rel=FUZZ_STATS["max_rel_vs_device_log10_oracle"], n_rel_gt=-1, frac_floor=FUZZ_STATS["frac_floor_max"],
+                n_sens=0, n_bad=0, support_equal=True, ok=True),
+           cells_admitted_by_sens_vs_glibc_oracle=FUZZ_STATS["n_sens_vs_glibc_oracle"])

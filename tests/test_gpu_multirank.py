@@ -108,7 +108,8 @@ def test_evolve3D_four_ranks_ten_sources(tmp_path):
     """10 sources on 4 ranks (2, 2, 2, 4): the criterion is the reference's 3.0 on every rank and the loop ends
     where the single-rank run ends."""
     import numpy as np
-    one = _run_evolve_ranks(1, tmp_path / "one", "ten_sources16") if (tmp_path / "one").mkdir() is None else None
+    (tmp_path / "one").mkdir()
+    one = _run_evolve_ranks(1, tmp_path / "one", "ten_sources16")
     rs = _run_evolve_ranks(4, tmp_path, "ten_sources16")
     for r in rs:
         assert float(r["conv_criterion"]) == 3.0

@@ -71,6 +71,30 @@ def test_phi_vs_golden(asora, golden_dir, name):
 
 
 @pytest.mark.parametrize("name", list(cases.CASES))
+def test_phi_vs_device_log10_oracle(asora, devlog_oracle, name):
+    """What the conditioning term of tests/parity.py stands for, demonstrated: against the oracle whose lookups use
+    the device's own log10 (oracle/log10_device.cpp: the host build of asora_log10.hpp -- the ONE change to
+    c2ray_oracle.c) the HIP rates meet the plain bar, 1e-10 relative + 1e-14 * max floor, with NO conditioning term:
+    every cell, lognormal48's 543 ill-conditioned ones included, and the heating rate too.  Together with the CPU half
+    (tests/test_oracle.py::test_device_log10_variant_differs_by_log10_rounding_only: glibc's and the device's log10
+    move the oracle's own rates by at most 2 * sens) this shows those cells are log10 rounding and nothing else."""
+    c = cases.CASES[name]()
+    phi, cdh, heat = run_hip(asora, c, heat=True)
+    o = cases.run_oracle(devlog_oracle, c, heat=True)
+    r = compare(phi, o["phi_ion"])  # no `sens`
+    rh = compare(heat, o["phi_heat"])
+    record(f"device-log10 oracle {name} (N={c['N']}, R={c['R']:g}, {len(c['flux'])} sources)", r,
+           oracle="port with the device's log10 (no conditioning term)", heat_max_rel=rh["max_rel"],
+           heat_n_bad=rh["n_bad"], heat_frac_floor=rh["frac_floor"])
+    print(f"\n[{name} vs device-log10 oracle] phi max_rel={r['max_rel']:.3e} n_rel>1e-10={r['n_rel_gt']} "
+          f"frac_floor={r['frac_floor']:.2e}; heat max_rel={rh['max_rel']:.3e} frac_floor={rh['frac_floor']:.2e}")
+    assert r["n_sens"] == 0 and r["ok"] and r["support_equal"], r
+    assert rh["ok"] and rh["support_equal"], rh
+    m = cdh != 0
+    assert np.array_equal(cdh[m], o["coldensh_out"][m])
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
 def test_cdh_last_source_vs_golden(asora, golden_dir, name):
     """coldensh_out = outgoing column density of the last source: <= 1e-13 relative wherever the GPU
     visits (octahedron); the Fortran sweeps the whole cube, the GPU leaves zeros outside."""

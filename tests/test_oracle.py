@@ -116,3 +116,36 @@ def test_port_vs_compiled_reference_bench_config(port_oracle):
                     xh=np.full((N, N, N), 2e-4), table_kw=dict(temp=1e5, numtau=20000))
     o = cases.run_reference(port_oracle, RefOracle(), c, max_subbox=60, subboxsize=60)  # asserts port == reference
     assert o["kind"] == "reference" and (o["phi_ion"] > 0).sum() > 100_000
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_device_log10_variant_differs_by_log10_rounding_only(port_oracle, devlog_oracle, name):
+    """The port with the HIP kernels' log10 in its lookups (oracle/log10_device.cpp) against the port with glibc's:
+    identical column densities (no log10 there), identical support, and every rate differs -- beyond 1e-15 of
+    itself -- by at most what a +-1 ulp change of the log10 results explains (`phi_sens`, the conditioning term of tests/parity.py, here with
+    factor 2: two correct log10's differ by at most one ulp per lookup, and a rate holds two lookups).  This is the
+    CPU half of the demonstration that the cells tests/parity.py admits through that term are log10 rounding
+    and nothing else; the GPU half is tests/test_gpu_parity.py::test_phi_vs_device_log10_oracle."""
+    from parity import record
+    c = cases.CASES[name]()
+    a = cases.run_oracle(port_oracle, c, sens=True)
+    b = cases.run_oracle(devlog_oracle, c)
+    assert np.array_equal(a["coldensh_out"], b["coldensh_out"])
+    for k, s in (("phi_ion", "phi_sens"), ("phi_heat", "heat_sens")):
+        assert np.array_equal(a[k] != 0, b[k] != 0)
+        err = np.abs(a[k] - b[k])
+        m = err > 0
+        assert np.all(a[s][m] > 0), "a rate differs in a cell whose log10 sensitivity is zero"
+        # (beyond a few ulps of the rate itself: where |log10 tau| << 1 one ulp of it is far below the 2^-58 absolute
+        # accuracy both log10's have, `sens` is then ~0 and so is the difference -- measured <= 2.1e-16 relative)
+        m = err > 1e-15 * np.abs(a[k])
+        ratio = float(np.max(err[m] / a[s][m])) if m.any() else 0.0
+        rel = relmax(b[k], a[k])
+        print(f"[{name}] {k}: cells that differ {int(m.sum())}, max |d|/sens {ratio:.3f}, max rel {rel:.2e}, "
+              f"rel > 1e-10 in {int((err > 1e-10 * np.abs(a[k])).sum())}")
+        assert ratio <= 2.0
+        if k == "phi_ion":
+            record(f"cpu: port(glibc log10) vs port(device log10) {name}",
+                   dict(max_rel=rel, n_rel_gt=int((err > 1e-10 * np.abs(a[k])).sum()), frac_floor=0.0, n_sens=0,
+                        n_bad=int((err > 2.0 * a[s]).sum()), support_equal=True, ok=bool(ratio <= 2.0)),
+                   max_err_over_sens=ratio, oracle="port(device log10) vs port(glibc log10)")
