@@ -21,6 +21,10 @@ roofline   = algorithmic bytes (32 B per visit + 16 B per rate-producing visit, 
              one sweep-kernel launch / its HIP-event duration (events recorded by the library on
              the launch stream, averaged over the timed steps), against 8 TB/s.
 cpu_baseline = the oracle timed on this node's host cores on a bounded sample (rank 0, N = 1 only).
+secondary  = (N = 1, default workload only) the regimes the headline does not show, each a few device-resident
+             steps timed by the same HIP events: clustered sources, the heating output, the reference's own
+             published point (N = 200, R = 10), BASELINE configs [0], [3], [4] on one GPU, small and large radii.
+             Same `frac` definition as `roofline`; `value` / `roofline` are untouched by it.
 """
 from __future__ import annotations
 
@@ -84,6 +88,118 @@ def cpu_baseline(a):
                        f"processes x {a.cpu_sources_per_core} sources, raytrace time {r['seconds']:.1f} s")}
 
 
+def _clustered_inputs(N, nsrc, base256=None):
+    """Log-normal density and sources drawn with probability ~ ndens^2.  512^3: the periodic
+    256^3 field tiled twice per axis (an FFT of 512^3 costs more than all the timed steps together)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cases import lognormal_density
+    if N == 512:
+        f = base256 if base256 is not None else lognormal_density(256, 7, smooth=2.0)
+        ndens = np.ascontiguousarray(np.tile(f, (2, 2, 2)))
+    elif N == 256 and base256 is not None:
+        ndens = base256
+    else:
+        ndens = lognormal_density(N, 7, smooth=2.0)
+    p = (ndens ** 2).ravel()
+    cdf = np.cumsum(p)
+    idx = np.searchsorted(cdf, np.random.default_rng(11).random(nsrc) * cdf[-1])
+    pos = np.stack(np.unravel_index(np.minimum(idx, p.size - 1), (N, N, N)), axis=1).astype(np.int32)
+    return ndens, pos
+
+
+# (label, N, sources, R, density, heat, cdh) -- the headline's table, cell size and xHII throughout
+SECONDARY = [
+    ("256^3 clustered grid, 1e4 clustered sources, R=60", 256, 10000, 60.0, "clustered", False, False),
+    ("headline workload + photo-heating output", 256, 10000, 60.0, "uniform", True, False),
+    ("headline workload + coldensh_out exported (what the host API does)", 256, 10000, 60.0, "uniform", False, True),
+    ("reference's published point: N=200, R=10, 1e5 sources", 200, 100000, 10.0, "uniform", False, False),
+    ("BASELINE configs[3] share: 250^3 clustered, 12500 sources, R=58.6", 250, 12500, 58.6, "clustered", False, False),
+    ("BASELINE configs[4] share: 512^3 clustered, 500 sources, R=150", 512, 500, 150.0, "clustered", False, False),
+    ("BASELINE configs[0]/[2]: 128^3 full box, 1 source", 128, 1, 150.0, "uniform", False, False),
+    ("256^3 uniform, 1e4 sources, R=3", 256, 10000, 3.0, "uniform", False, False),
+    ("256^3 uniform, 1e4 sources, R=5", 256, 10000, 5.0, "uniform", False, False),
+    ("256^3 uniform, 1e4 sources, R=10", 256, 10000, 10.0, "uniform", False, False),
+    ("256^3 uniform, 1e4 sources, R=30", 256, 10000, 30.0, "uniform", False, False),
+    ("256^3 uniform, 1000 sources, R=10 (short call: fixed per-call kernels)", 256, 1000, 10.0, "uniform", False, False),
+    ("256^3 uniform, 1000 sources, R=160", 256, 1000, 160.0, "uniform", False, False),
+]
+
+
+def secondary_runs(a, asora, torch, dev, inp, steps=3, warmup=1):
+    """The regimes beside the headline.  Every entry: device-resident inputs, `warmup` + `steps`
+    calls of asora_do_all_sources_dev, kernel time from the library's HIP events on the launch stream, wall time per
+    call from the host clock around synchronised steps."""
+    out = []
+    stream = torch.cuda.current_stream().cuda_stream
+    num_tau = inp["thin"].shape[0]
+    base256 = None
+    hthin = hthick = None
+    for label, N, nsrc, R, density, heat, cdh in SECONDARY:
+        try:
+            rng = np.random.default_rng(918)
+            if density == "uniform":
+                ndens = np.full((N, N, N), 1e-3)
+                pos = rng.integers(0, N, (nsrc, 3)).astype(np.int32)
+            else:
+                if base256 is None and N in (256, 512):
+                    base256, _ = _clustered_inputs(256, 1)
+                ndens, pos = _clustered_inputs(N, nsrc, base256)
+            flux = 4.09e40 * rng.uniform(1e9, 5e11, nsrc) / 1e48
+            asora.device_init(N, 64, dev.index, torch.cuda.device_count())
+            asora.photo_table_to_device(np.ascontiguousarray(inp["thin"]), np.ascontiguousarray(inp["thick"]), num_tau)
+            if heat:
+                if hthin is None:
+                    from pyc2ray_amd.radiation import EV, H_PLANCK, BlackBodySource, make_tau_table
+                    fmin, fmax = 13.598 * EV / H_PLANCK, 54.416 * EV / H_PLANCK
+                    tau, _ = make_tau_table(-20.0, 4.0, a.numtau)
+                    hthin, hthick = BlackBodySource(1e5, False, fmin, 2.8).make_heat_table(tau, fmin, fmax, 1e48)
+                asora.heat_table_to_device(np.ascontiguousarray(hthin), np.ascontiguousarray(hthick), num_tau)
+            ndens_t = torch.from_numpy(np.ascontiguousarray(ndens).ravel()).to(dev)
+            xh_t = torch.full((N ** 3,), a.xh, dtype=torch.float64, device=dev)
+            phi_t = torch.zeros(N ** 3, dtype=torch.float64, device=dev)
+            heat_t = torch.zeros(N ** 3, dtype=torch.float64, device=dev) if heat else None
+            cdh_t = torch.zeros(N ** 3, dtype=torch.float64, device=dev) if cdh else None
+            asora.density_from_device(ndens_t.data_ptr(), N)
+            asora.source_data_to_device(np.ascontiguousarray(pos.ravel()), np.ascontiguousarray(flux), nsrc)
+
+            def call():
+                asora.do_all_sources_dev(R, cdh_t.data_ptr() if cdh else 0, 6.30e-18, a.dr, xh_t.data_ptr(),
+                                         phi_t.data_ptr(), heat_t.data_ptr() if heat else 0, nsrc, N, -20.0,
+                                         inp["dlogtau"], num_tau, stream)
+            for _ in range(warmup):
+                call()
+            torch.cuda.synchronize()
+            k_ms, t0 = [], time.perf_counter()
+            for _ in range(steps):
+                call()
+                k_ms.append(asora.last_sweep_ms())
+            torch.cuda.synchronize()
+            wall_ms = (time.perf_counter() - t0) / steps * 1e3
+            k = float(np.mean(k_ms))
+            visits, _ = asora.visit_count(R, N)
+            in_sphere = asora.geometry_census(R, a.dr, N)["owned_rate"]
+            algo = (32.0 * visits + (32.0 if heat else 16.0) * in_sphere) * nsrc
+            info = asora.last_launch_info()
+            e = {"workload": label, "N": N, "sources": nsrc, "R": R, "kernel_ms": k, "ms_per_step": wall_ms,
+                 "updates_per_s": float(visits) * nsrc / (k * 1e-3), "frac": algo / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "visits_per_source": visits, "rate_visits_per_source": in_sphere,
+                 "launch": f"{info['block']} thr, {info['staging']}, {info['sectors_per_workgroup']} sector(s) x "
+                           f"{info['sources_per_workgroup']} source(s), {info['lds_bytes']} B LDS"
+                           + ("" if info["table_driven"] else " [table-free fallback kernel]")}
+            if N == 200:  # the reference's own unit (docs/fig/scaling.jpg): published 1.466 ns (A100), 1.081 ns (GH200)
+                e["ns_per_source_per_sphere_cell"] = wall_ms * 1e-3 / nsrc / (4.0 / 3.0 * np.pi * R ** 3) * 1e9
+            out.append(e)
+            del ndens_t, xh_t, phi_t, heat_t, cdh_t
+        except Exception as ex:  # a secondary line never costs the headline
+            out.append({"workload": label, "error": f"{type(ex).__name__}: {ex}"})
+        finally:
+            try:
+                asora.device_close()
+            except Exception:
+                pass
+    return out
+
+
 def _mark(msg):
     if os.environ.get("ASORA_BENCH_DEBUG"):
         import faulthandler
@@ -113,6 +229,8 @@ def main():
                     help="form the process group, count the ranks, print {n_gpus, ranks_seen, backend} and exit "
                          "(no GPU work: checks the launcher / rendezvous path of a node)")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
+    ap.add_argument("--secondary", choices=["auto", "on", "off"], default="auto",
+                    help="the `secondary` list of the JSON line (auto: with the default workload on one GPU)")
     ap.add_argument("--cpu-sources-per-core", type=int, default=48)  # ~15 s of CPU work per core
     a = ap.parse_args()
 
@@ -321,6 +439,13 @@ def main():
                     "ns_per_source_per_sphere_cell": min(hs[1:]) / a.sources / (4.0 / 3.0 * np.pi * a.R ** 3) * 1e9,
                     "what": "asora_do_all_sources on host pointers: H2D xh_av + sweep + D2H phi_ion and coldensh_out"}
     asora.device_close()
+    secondary = None
+    default_workload = (N == 256 and a.sources == 10000 and a.R == 60.0 and a.density == "uniform" and not a.heat
+                        and not os.environ.get("ASORA_OPTIONS"))
+    if rank == 0 and world == 1 and not emu and not dist_on and (a.secondary == "on" or (a.secondary == "auto" and default_workload)):
+        del ndens_t, xh_t, phi_t
+        _mark("secondary runs")
+        secondary = secondary_runs(a, asora, torch, dev, inp)
     # second denominator: what a plain device-to-device copy achieves on this box
     copy_gbs = None
     if rank == 0:
@@ -369,6 +494,8 @@ def main():
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes,
                          "launch": info},
         }
+        if secondary is not None:
+            line["secondary"] = secondary
         if host_api is not None:
             line["host_api"] = host_api
         if cpu is not None:

@@ -200,6 +200,13 @@ int asora_set_option(const char *name, long long value);
 /* 1 if the last sweep ran the table-driven kernel, 0 for the table-free one. */
 int asora_last_sweep_is_table_driven(void);
 
+/* One line saying why the last sweep ran the (about 3x slower) table-free kernel, "" when it ran the table-driven
+ * one.  The table-driven kernel addresses the grids with 32-bit byte offsets, 10-bit in-plane coordinates and
+ * 16-bit staging positions: meshes of 2^28 cells or more (N >= 646), plane extents >= 1024 cells, more than 65535
+ * staged entries per sector or geometry tables beyond "max_table_cells" take the fallback.  No counterpart in the
+ * reference (diagnostics of this library).  The pointer stays valid until the next sweep. */
+const char *asora_last_launch_notice(void);
+
 /* Device self-test: counts the inputs for which the kernels' division helpers (div_exact,
  * rcp_exact, div_const) differ in any bit from the compiler's IEEE-754 division num[i]/den[i]. */
 int asora_test_division(const double *num, const double *den, long long n, long long *mismatch_div,

@@ -75,6 +75,7 @@ struct Options {
     long long max_table_cells = 48LL << 20;  // option "max_table_cells": beyond this the generic kernel runs
 };
 struct LaunchRecord {
+    std::string notice;  // one line when the last sweep could not use the table-driven kernel (asora_last_launch_notice)
     int last_tab = 0;
     int last_grid = 0, last_block = 0, last_lds = 0, last_is_lds = 1;
 };
@@ -524,9 +525,24 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     // the table-driven kernel needs 32-bit cell offsets, 10-bit in-plane coordinates and 16-bit staging positions
     bool use_tab = !S.opt.force_generic && S.cells < (1ULL << 28) && wmax < 1024 &&
                    8 * geometry_cells_per_variant(A.q_max, std::max(A.last_l, A.last_r), nmaxmax) <= S.opt.max_table_cells;
+    S.rec.notice.clear();
+    if (!use_tab) {
+        char buf[256];
+        if (S.opt.force_generic) std::snprintf(buf, sizeof buf, "table-free kernel: option force_generic");
+        else if (S.cells >= (1ULL << 28))
+            std::snprintf(buf, sizeof buf, "table-free fallback kernel (about 3x slower): %d^3 cells >= 2^28, the table-driven "
+                          "kernel addresses the grids with 32-bit byte offsets (N <= 645)", N);
+        else if (wmax >= 1024) std::snprintf(buf, sizeof buf, "table-free fallback kernel: plane extent %d >= 1024", wmax);
+        else std::snprintf(buf, sizeof buf, "table-free fallback kernel: geometry tables beyond option max_table_cells = %lld",
+                           S.opt.max_table_cells);
+        S.rec.notice = buf;
+    }
     if (use_tab && num_src > 0) {
         if (int rc2 = build_geometry(N, R, dr, A.q_max, A.last_l, A.last_r, st)) return rc2;
-        if (S.geo_entries > 65535) use_tab = false;
+        if (S.geo_entries > 65535) {
+            use_tab = false;
+            S.rec.notice = "table-free fallback kernel: more than 65535 staged entries per sector (16-bit staging positions)";
+        }
     }
     size_t lds_stage, lds_stage_c = 0, lds_fixed;
     bool quad = false;
@@ -662,7 +678,13 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         const int want = S.opt.stride_residue >= 0 ? S.opt.stride_residue % 32 : (qshift == 3 ? 2 : 4);
         int delta = ((want - A.cw_entries) % mod + mod) % mod;
         if (sshift && S.opt.stride_residue < 0) delta = A.cw_entries % 16 == 0 ? 1 : 0;
-        const size_t lds2 = lds + (size_t)delta * ((size_t)1 << (qshift + sshift)) * (compact ? 8 : 16);
+        // (the size is formed from the padded entry count exactly as the kernel lays it out: column-density-only
+        // staging rounds the array of each sector up to an even number of doubles)
+        auto staged_bytes = [&](int entries) {
+            const size_t arrays = (size_t)1 << (qshift + sshift);
+            return arrays * (compact ? (size_t)((entries + 1) & ~1) * sizeof(double) : (size_t)entries * 2 * sizeof(double));
+        };
+        const size_t lds2 = lds - staged_bytes(A.cw_entries) + staged_bytes(A.cw_entries + delta);
         auto per_cu = [&](size_t b) { return (size_t)S.max_lds / ((b + 1023) & ~(size_t)1023); };
         if (delta && lds2 <= (size_t)S.max_lds && per_cu(lds2) == per_cu(lds)) {
             A.cw_entries += delta;
@@ -800,13 +822,23 @@ int stager_setup(int want) {
     want = std::min(want, (int)Stager::MAXT);
     if (G.nthreads == want) return 0;
     stager_release();
-    HIP_TRY(hipHostMalloc((void **)&G.pinned, (size_t)want * Stager::SLOTS * Stager::CHUNK, hipHostMallocDefault));
-    G.nthreads = want;
-    for (int t = 0; t < want; t++) {
-        HIP_TRY(hipStreamCreateWithFlags(&G.stream[t], hipStreamNonBlocking));
-        for (int k = 0; k < Stager::SLOTS; k++) HIP_TRY(hipEventCreateWithFlags(&G.event[t][k], hipEventDisableTiming));
+    // nthreads counts what stager_release has to visit; a failure half-way gives everything back, so the next call
+    // starts from scratch instead of finding nthreads == want with null streams / events
+    const int rc = [&]() -> int {
+        HIP_TRY(hipHostMalloc((void **)&G.pinned, (size_t)want * Stager::SLOTS * Stager::CHUNK, hipHostMallocDefault));
+        G.nthreads = want;
+        for (int t = 0; t < want; t++) {
+            HIP_TRY(hipStreamCreateWithFlags(&G.stream[t], hipStreamNonBlocking));
+            for (int k = 0; k < Stager::SLOTS; k++) HIP_TRY(hipEventCreateWithFlags(&G.event[t][k], hipEventDisableTiming));
+        }
+        return 0;
+    }();
+    if (rc) {
+        const std::string msg = g_err;
+        stager_release();
+        g_err = msg;
     }
-    return 0;
+    return rc;
 }
 
 // dir: true = host -> device.  All device work issued before the call must have completed (the worker streams do
@@ -853,9 +885,19 @@ int staged_copy(void *dev, void *host, size_t bytes, bool to_device) {
         if (e == hipSuccess) e = hipStreamSynchronize(G.stream[t]);
         if (e != hipSuccess) err.store((int)e);
     };
+    // (thread creation can throw std::system_error; nothing may cross the extern "C" boundary: the chunks of a thread
+    // that did not start are copied by this one)
     std::vector<std::thread> pool;
-    for (int t = 1; t < G.nthreads; t++) pool.emplace_back(worker, t);
+    std::vector<int> not_started;
+    for (int t = 1; t < G.nthreads; t++) {
+        try {
+            pool.emplace_back(worker, t);
+        } catch (...) {
+            not_started.push_back(t);
+        }
+    }
     worker(0);
+    for (int t : not_started) worker(t);
     for (auto &th : pool) th.join();
     if (err.load()) return fail(100 + err.load(), "asora_do_all_sources: staged %s copy failed: %s", to_device ? "upload" : "download",
                                 hipGetErrorString((hipError_t)err.load()));
@@ -1294,6 +1336,8 @@ int asora_set_option(const char *name, long long value) {
 }
 
 int asora_last_sweep_is_table_driven(void) { return S.rec.last_tab; }
+
+const char *asora_last_launch_notice(void) { return S.rec.notice.c_str(); }
 
 int asora_test_division(const double *num, const double *den, long long n, long long *mismatch_div,
                         long long *mismatch_rcp, long long *mismatch_const) {

@@ -70,6 +70,7 @@ ABI = {
     "asora_set_option": (C.c_int, [C.c_char_p, C.c_longlong]),
     "asora_source_order": (C.c_int, [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "asora_last_sweep_is_table_driven": (C.c_int, []),
+    "asora_last_launch_notice": (C.c_char_p, []),
     "asora_test_division": (C.c_int, [_dp, _dp, C.c_longlong] + [C.POINTER(C.c_longlong)] * 3),
     "asora_last_error": (C.c_char_p, []),
 }
@@ -300,4 +301,5 @@ def last_launch_info():
     _check(_lib.asora_last_launch_info(C.byref(g), C.byref(b), C.byref(l), C.byref(s)))
     return dict(grid=g.value, block=b.value, lds_bytes=l.value, staging={0: "global", 1: "lds", 2: "lds-compact"}[s.value & 3], quad=bool((s.value >> 2) & 3), sectors_per_workgroup=1 << ((s.value >> 2) & 3),
                 sources_per_workgroup=1 << ((s.value >> 4) & 3),
-                table_driven=bool(_lib.asora_last_sweep_is_table_driven()))
+                table_driven=bool(_lib.asora_last_sweep_is_table_driven()),
+                notice=_lib.asora_last_launch_notice().decode())

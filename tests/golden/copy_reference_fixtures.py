@@ -6,6 +6,12 @@
 and writes the optical-depth grid of the reference's own ``make_tau_table`` (pyc2ray/radiation/common.py:11-35, a
 numpy-only file that loads stand-alone) for the three table shapes the tests and the bench use.  Data only: inputs
 and expected outputs.  Loaded with numpy.load(allow_pickle=False).
+
+Note on the import below: it EXECUTES pyc2ray/radiation/common.py from the (untrusted) reference tree in this
+interpreter.  That file was read in full before this script was first run: it imports numpy only, sets one constant and
+defines ``make_tau_table`` (35 lines: ``10 ** (minlogtau + arange * dlogtau)`` behind a leading 0); no I/O, no
+subprocess, no network.  The point of the .npz is to pin pyc2ray_amd.radiation.make_tau_table against the OUTPUT of the reference's
+generator, which a restatement of those lines could not do.  Build container only; nothing on the GPU box runs this.
 """
 import importlib.util
 import os

@@ -233,6 +233,25 @@ def test_table_driven_equals_table_free_kernel(asora, golden_dir, name):
     assert np.array_equal(phi_t, phi_g)
 
 
+def test_fallback_kernel_leaves_a_notice(asora, golden_dir):
+    """The table-free kernel never runs silently: asora_last_launch_notice names the reason
+    -- here the two that a small mesh can provoke, the option and the geometry-table budget; the 2^28-cell limit
+    goes through the same code -- and is empty on the fast path."""
+    c = load_golden(golden_dir, "rcut7p3")
+    run_hip(asora, c, num_src=1)
+    assert asora.last_launch_info()["notice"] == "" and asora.last_launch_info()["table_driven"]
+    for opt, val, restore, word in (("force_generic", 1, 0, "force_generic"), ("max_table_cells", 10, 48 << 20, "max_table_cells")):
+        asora.set_option(opt, val)
+        try:
+            run_hip(asora, c, num_src=1)
+            info = asora.last_launch_info()
+        finally:
+            asora.set_option(opt, restore)
+        assert not info["table_driven"] and word in info["notice"], info
+    run_hip(asora, c, num_src=1)
+    assert asora.last_launch_info()["notice"] == ""
+
+
 @pytest.mark.parametrize("threads", [64, 128, 192, 512, 1024])
 @pytest.mark.parametrize("name", ["corner32", "lognormal48", "rcut7p3", "thick24"])
 def test_workgroup_sizes_equal_256_threads(asora, golden_dir, name, threads):
