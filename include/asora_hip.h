@@ -166,7 +166,8 @@ int asora_last_sweep_ms(float *ms);
 /* Launch geometry of the last sweep (for profile matching): workgroups, threads per workgroup, dynamic LDS
  * bytes per workgroup, and where the staged column densities lived: 0 global scratch, 1 LDS as (column
  * density, weight) pairs, 2 LDS as column densities only; +4 * log2(sectors per workgroup) when the four-quadrant /
- * eight-octant kernel ran; +16 * log2(sources per workgroup) when it took several sources side by side. */
+ * eight-octant kernel ran; +16 * log2(sources per workgroup) when it took several sources side by side; +64 when the call
+ * ran on one grid layout (option "single_layout"). */
 int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_is_lds);
 
 /* Tuning / test switches: "force_generic" (1: always run the table-free sweep kernel),
@@ -193,6 +194,10 @@ int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_i
  * "skip_saturated" (1: cells behind an optical depth beyond the photo table's last entry -- where both look-ups of
  * photo_lookuptable clamp to that entry and the rate is exactly +0, photorates.f90:140-146 -- evaluate no rates;
  * identical results; LDS-staged single-sector kernels of >= 256 threads only; off by default),
+ * "single_layout" (0 = automatic: calls of up to "single_max_visits" (source, cell) visits (default 0: 1.2 per cell of the mesh) at R <~ 46 and all calls with q_max <= 10 run on ONE grid
+ * layout -- the z-dominant sectors address the [i][j][k] grids with a stride, the sweep adds straight into the caller's
+ * grids, and the per-call passes shrink from 9 to 4 N^3 doubles of traffic; 1: whenever the table-driven kernel runs;
+ * -1: never.  Same arithmetic per cell: bit-identical for a single source),
  * "copy_threads" (host threads staging the grids of the host-pointer entry points through page-locked memory,
  * default 4, 0: plain hipMemcpy), "lds_pad" (extra LDS per workgroup, occupancy experiments). */
 int asora_set_option(const char *name, long long value);

@@ -71,6 +71,8 @@ struct Options {
     int compact_staging = 0;      // option "compact_staging": stage column densities only (0: automatic, 1: always, -1: never)
     int skip_unobserved = 0;      // option "skip_unobserved": cells outside the R-sphere only for the exported column density
     int skip_saturated = 0;       // option "skip_saturated": no rate evaluation behind optical depths beyond the table's end
+    int single_layout = 0;        // option "single_layout": z-dominant sectors on the [i][j][k] grids too, no transposed copies / merge pass (0: automatic, short calls; 1: whenever the table-driven kernel runs; -1: never)
+    long long single_max_visits = 0;  // option "single_max_visits": automatic choice up to this many (source, cell) visits per call (0: 1.2 x the cells of the mesh)
     int force_generic = 0;        // option "force_generic": always use the table-free kernel
     long long max_table_cells = 48LL << 20;  // option "max_table_cells": beyond this the generic kernel runs
 };
@@ -112,6 +114,7 @@ struct State {
     uint2 *cell_meta_dev = nullptr;
     double2 *cell_geo_dev = nullptr;
     int geo_N = 0, geo_nplanes = 0, geo_entries = 0, geo_vmap[8] = {0}, geo_nmax_rate = 0;
+    long long geo_visits = -1, geo_in_sphere = -1;  // asora_visit_count of the cached geometry (-1: not counted yet)
     double geo_R = -1.0, geo_dr = -1.0;
     bool geo_valid = false;
     double *log10_table = nullptr;  // asora_log10.hpp table
@@ -352,6 +355,7 @@ int build_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
     S.geo_nmax_rate = 0;
     for (size_t i = 0; i < G.planes.size(); i++)
         if (G.planes[i].cntA > 0) S.geo_nmax_rate = std::max(S.geo_nmax_rate, (int)(i % (size_t)G.nplanes));
+    S.geo_visits = S.geo_in_sphere = -1;
     S.geo_N = N; S.geo_R = R; S.geo_dr = dr; S.geo_nplanes = G.nplanes; S.geo_entries = G.entries_max; S.geo_valid = true;
     return 0;
 }
@@ -469,34 +473,10 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
     const size_t bytes = S.cells * sizeof(double);
     const bool want_heat = heat_out_dev != nullptr;
     const bool want_cdh = cdh_out_dev != nullptr;
-    if (want_heat) {
-        if (int rc = alloc_grid(S.heatA)) return rc;
-        if (int rc = alloc_grid(S.heatB)) return rc;
-    }
-    if (want_cdh) {
-        if (int rc = alloc_grid(S.cdhA)) return rc;
-        if (int rc = alloc_grid(S.cdhB)) return rc;
-    }
-
     const dim3 tb(32, 8), tg((N + 31) / 32, (N + 31) / 32, N);
-    hipLaunchKernelGGL(asora::prep_nhi_kernel, tg, tb, 0, st, S.n_dev, xh_dev, S.nhiA, S.nhiB, N);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(S.phiA, 0, bytes, st));
-    HIP_TRY(hipMemsetAsync(S.phiB, 0, bytes, st));
-    if (want_heat) {
-        HIP_TRY(hipMemsetAsync(S.heatA, 0, bytes, st));
-        HIP_TRY(hipMemsetAsync(S.heatB, 0, bytes, st));
-    }
-    if (want_cdh) {
-        HIP_TRY(hipMemsetAsync(S.cdhA, 0, bytes, st));
-        HIP_TRY(hipMemsetAsync(S.cdhB, 0, bytes, st));
-    }
 
     asora::SweepArgs A;
     std::memset(&A, 0, sizeof A);
-    A.nhiA = S.nhiA; A.nhiB = S.nhiB; A.phiA = S.phiA; A.phiB = S.phiB;
-    A.heatA = want_heat ? S.heatA : nullptr; A.heatB = want_heat ? S.heatB : nullptr;
-    A.cdhA = want_cdh ? S.cdhA : nullptr; A.cdhB = want_cdh ? S.cdhB : nullptr;
     A.src_pos = S.src_pos; A.src_flux = S.src_flux;
     A.thick = S.thick; A.thin = S.thin; A.hthick = S.hthick; A.hthin = S.hthin;
     A.log10_table = S.log10_table;
@@ -543,6 +523,63 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             use_tab = false;
             S.rec.notice = "table-free fallback kernel: more than 65535 staged entries per sector (16-bit staging positions)";
         }
+    }
+    // Grid layouts.  Usually two: the neutral density and the rate accumulators exist as [i][j][k] and as the transposed
+    // [i][k][j], in which the z-dominant sectors' in-plane coordinate is contiguous, and a merge pass adds the two rate
+    // grids into the caller's -- 9 N^3 doubles of streaming traffic per call whatever the list holds (256^3: 0.23 ms).
+    // A short call (few sources or a small radius: option "single_max_visits") runs on ONE layout instead: the
+    // z-dominant sectors address the [i][j][k] grids with a stride (their rows are short at such radii anyway), the sweep
+    // adds straight into the caller's grids, and what is left per call is one pass that forms the neutral density and
+    // zeroes the outputs -- 4 N^3 doubles.  Measured at 256^3 (profiles/small_r_probe.py, two layouts -> one): the fixed
+    // passes 0.23 -> 0.11 ms per call; the sweep itself R = 3 0.133 -> 0.116 ms and R = 5 0.268 -> 0.251 ms per 1e4 sources
+    // (faster: no second grid to miss in), R = 10 +15 %, R = 15 +30 %, R = 20 +46 %, R = 30 +65 % (64 lanes of a z-sector
+    // in 64 cache lines) -- about 4e-3 ns per visit against 5 N^3 doubles of traffic saved, so the automatic choice
+    // takes one layout up to 1.2 visits per cell of the mesh (256^3: 2e7 visits per call) at the radii of the
+    // multi-sector kernels (R <~ 46; the long rows of larger radii lose more: 128^3 full box, one source, 0.23 -> 0.28 ms),
+    // and whenever q_max <= 10 (R <= 5.7 cells).
+    if (use_tab && num_src > 0 && S.geo_visits < 0) (void)asora_visit_count(R, N, &S.geo_visits, &S.geo_in_sphere);
+    const bool single = use_tab && num_src > 0 &&
+                        (S.opt.single_layout > 0 ||
+                         (S.opt.single_layout == 0 && S.geo_entries <= S.opt.quad_max_entries &&
+                          (S.geo_visits * (long long)num_src <=
+                               (S.opt.single_max_visits > 0 ? S.opt.single_max_visits : (long long)(1.2 * (double)S.cells)) ||
+                           A.q_max <= 10)));
+    if (single) {
+        const bool vec = ((reinterpret_cast<uintptr_t>(S.n_dev) | reinterpret_cast<uintptr_t>(xh_dev) |
+                           reinterpret_cast<uintptr_t>(phi_out_dev) | reinterpret_cast<uintptr_t>(heat_out_dev) |
+                           reinterpret_cast<uintptr_t>(cdh_out_dev)) & 15) == 0 && S.cells % 2 == 0;
+        const int pgrid = (int)std::min<size_t>((S.cells / (vec ? 2 : 1) + 255) / 256, (size_t)S.num_cu * 64);
+        if (vec) hipLaunchKernelGGL(asora::prep_single_kernel<true>, dim3(pgrid), dim3(256), 0, st, S.n_dev, xh_dev, S.nhiA,
+                                    phi_out_dev, heat_out_dev, cdh_out_dev, S.cells);
+        else hipLaunchKernelGGL(asora::prep_single_kernel<false>, dim3(pgrid), dim3(256), 0, st, S.n_dev, xh_dev, S.nhiA,
+                                phi_out_dev, heat_out_dev, cdh_out_dev, S.cells);
+        HIP_TRY(hipGetLastError());
+        A.single = 1;
+        A.nhiA = S.nhiA; A.phiA = phi_out_dev; A.heatA = heat_out_dev; A.cdhA = cdh_out_dev;
+    } else {
+        if (want_heat) {
+            if (int rc = alloc_grid(S.heatA)) return rc;
+            if (int rc = alloc_grid(S.heatB)) return rc;
+        }
+        if (want_cdh) {
+            if (int rc = alloc_grid(S.cdhA)) return rc;
+            if (int rc = alloc_grid(S.cdhB)) return rc;
+        }
+        hipLaunchKernelGGL(asora::prep_nhi_kernel, tg, tb, 0, st, S.n_dev, xh_dev, S.nhiA, S.nhiB, N);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(S.phiA, 0, bytes, st));
+        HIP_TRY(hipMemsetAsync(S.phiB, 0, bytes, st));
+        if (want_heat) {
+            HIP_TRY(hipMemsetAsync(S.heatA, 0, bytes, st));
+            HIP_TRY(hipMemsetAsync(S.heatB, 0, bytes, st));
+        }
+        if (want_cdh) {
+            HIP_TRY(hipMemsetAsync(S.cdhA, 0, bytes, st));
+            HIP_TRY(hipMemsetAsync(S.cdhB, 0, bytes, st));
+        }
+        A.nhiA = S.nhiA; A.nhiB = S.nhiB; A.phiA = S.phiA; A.phiB = S.phiB;
+        A.heatA = want_heat ? S.heatA : nullptr; A.heatB = want_heat ? S.heatB : nullptr;
+        A.cdhA = want_cdh ? S.cdhA : nullptr; A.cdhB = want_cdh ? S.cdhB : nullptr;
     }
     size_t lds_stage, lds_stage_c = 0, lds_fixed;
     bool quad = false;
@@ -769,8 +806,9 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
         HIP_TRY(hipEventRecord(S.ev1, st));
         S.timed = true;
         S.rec.last_grid = grid; S.rec.last_block = use_tab ? threads : asora::SWEEP_THREADS; S.rec.last_lds = (int)lds;
-        S.rec.last_is_lds = (use_lds ? (compact ? 2 : 1) : 0) | (qshift << 2) | (sshift << 4);
+        S.rec.last_is_lds = (use_lds ? (compact ? 2 : 1) : 0) | (qshift << 2) | (sshift << 4) | (single ? 64 : 0);
     }
+    if (single) return 0;  // the sweep has added straight into the caller's grids
 
     hipLaunchKernelGGL(asora::finalize_kernel, tg, tb, 0, st, S.phiA, S.phiB, phi_out_dev, N);
     HIP_TRY(hipGetLastError());
@@ -1330,6 +1368,8 @@ int asora_set_option(const char *name, long long value) {
     else if (!std::strcmp(name, "pack_max_entries")) S.opt.pack_max_entries = (int)value;
     else if (!std::strcmp(name, "skip_unobserved")) S.opt.skip_unobserved = value != 0;
     else if (!std::strcmp(name, "skip_saturated")) S.opt.skip_saturated = value != 0;
+    else if (!std::strcmp(name, "single_layout")) S.opt.single_layout = (int)value;
+    else if (!std::strcmp(name, "single_max_visits")) S.opt.single_max_visits = value;
     else if (!std::strcmp(name, "copy_threads")) g_copy_threads = (int)std::max<long long>(0, std::min<long long>(value, Stager::MAXT));
     else return fail(12, "asora_set_option: unknown option '%s'", name);
     return 0;

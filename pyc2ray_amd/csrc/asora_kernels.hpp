@@ -96,6 +96,8 @@ struct SweepArgs {
     int rate_only;             // option "skip_unobserved": sources other than cdh_src sweep list A only
     int nmax_rate;             // last plane with a cell inside the R-sphere
     double tau_sat;            // optical depth from which both table look-ups of a cell clamp to the last entry
+    int single;                // ONE grid layout (short calls): z-dominant sectors address the [i][j][k] grids too (nhiA / phiA /
+                               // heatA / cdhA, in-plane coordinate b strided by N); no transposed copies, no merge pass
 };
 
 // ------------------------------------------------------------------------------------------
@@ -499,6 +501,13 @@ __global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(SweepArgs A) {
 #ifndef ASORA_WAVES_PER_EU
 #define ASORA_WAVES_PER_EU 4
 #endif
+// ... of the variants with the heating rate as second output (their rate batch holds twice the table pairs)
+#ifndef ASORA_WAVES_PER_EU_HEAT
+#define ASORA_WAVES_PER_EU_HEAT ASORA_WAVES_PER_EU
+#endif
+#ifndef ASORA_HEAT_BATCH
+#define ASORA_HEAT_BATCH 0
+#endif
 
 // Element access at a 32-bit BYTE offset from a wave-uniform base: lets the compiler use the
 // "SGPR base + 32-bit VGPR offset" addressing mode instead of forming a 64-bit address per lane.
@@ -687,7 +696,8 @@ __device__ __forceinline__ void phase_barrier() {
 // column / interpolation tables (the interpolation carries the source's own coordinate), flux, position.
 // SATSKIP: option "skip_saturated" compiled in (single-sector kernels only; a run-time test costs the default path 2 %).
 template <bool LDS_STAGE, bool HEAT, int THREADS, bool WSTAGED, int QSHIFT = 0, int SSHIFT = 0, bool SATSKIP = false>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(ASORA_WAVES_PER_EU, ASORA_WAVES_PER_EU)))
+__global__ __launch_bounds__(THREADS)
+__attribute__((amdgpu_waves_per_eu(HEAT ? ASORA_WAVES_PER_EU_HEAT : ASORA_WAVES_PER_EU, HEAT ? ASORA_WAVES_PER_EU_HEAT : ASORA_WAVES_PER_EU)))
 void sweep_tab_kernel(SweepArgs A) {
     static_assert(!SATSKIP || QSHIFT == 0, "skip_saturated rides on the single-sector kernels");
     constexpr int P = ASORA_PHASE_CHUNKS, NW = THREADS / 64;
@@ -759,12 +769,16 @@ void sweep_tab_kernel(SweepArgs A) {
         else if (axis == 1) { p0 = j0; u0 = i0; v0 = k0; ur1 = i0r + 1; vr1 = k0r + 1; }
         else { p0 = i0; u0 = j0; v0 = k0; ur1 = j0r + 1; vr1 = k0r + 1; }
         const double flux = A.src_flux[src];
-        const double *__restrict__ nhi = (axis == 0) ? A.nhiB : A.nhiA;
-        double *__restrict__ phi = (axis == 0) ? A.phiB : A.phiA;
-        double *__restrict__ heat = (axis == 0) ? A.heatB : A.heatA;
+        // z-dominant sectors work on the transposed copies [i][k][j], where their in-plane coordinate b (= j) is the
+        // contiguous one -- unless the call runs on one layout (A.single: short calls, where the transposed copies and
+        // their merge pass would cost more than the strided accesses of these sectors)
+        const bool layoutB = axis == 0 && !A.single;
+        const double *__restrict__ nhi = layoutB ? A.nhiB : A.nhiA;
+        double *__restrict__ phi = layoutB ? A.phiB : A.phiA;
+        double *__restrict__ heat = layoutB ? A.heatB : A.heatA;
         // column-density export: wave-uniform pointer when the group holds the exported source, per-lane flag
         const bool cdh_group = PACK ? (A.cdh_src >= src0 && A.cdh_src < src0 + NSRC) : (src == A.cdh_src);
-        double *__restrict__ cdh = cdh_group ? ((axis == 0) ? A.cdhB : A.cdhA) : nullptr;
+        double *__restrict__ cdh = cdh_group ? (layoutB ? A.cdhB : A.cdhA) : nullptr;
         const bool cdh_lane = !PACK || src == A.cdh_src;
         const rsrc_t phi_rs = make_rsrc(phi, N2 * (uint32_t)N * 8u);
         const rsrc_t heat_rs = make_rsrc(HEAT ? heat : phi, N2 * (uint32_t)N * 8u);
@@ -777,8 +791,11 @@ void sweep_tab_kernel(SweepArgs A) {
         // (OCT: the host has checked q_max <= min(last_l, last_r): both pyramids march the same planes)
         const int nmax = min(min(OCT ? min(A.last_r, A.last_l) : (sp > 0 ? A.last_r : A.last_l), A.q_max),
                              rate_only ? A.nmax_rate : 0x7fffffff);
-        const uint32_t strideP = (axis == 2) ? N2 : (uint32_t)N;
+        // cell = p * strideP + u * strideU + v * strideV: x-sectors (p, u, v) = (i, j, k), y-sectors (j, i, k), z-sectors
+        // (k, i, j) -- in [i][k][j] unless A.single
+        const uint32_t strideP = (axis == 2) ? N2 : (axis == 0 && A.single) ? 1u : (uint32_t)N;
         const uint32_t strideU = (axis == 2) ? (uint32_t)N : N2;
+        const uint32_t strideV = (axis == 0 && A.single) ? (uint32_t)N : 1u;
         // (QUAD: the host has checked that the four quadrants share their variant)
         const int variant = QUAD ? A.vmap[axis != 0 ? 1 : 0]
                                  : A.vmap[(((su < 0) ? 2 : 0) + ((sv < 0) ? 1 : 0)) * 2 + (axis != 0 ? 1 : 0)];
@@ -819,7 +836,7 @@ void sweep_tab_kernel(SweepArgs A) {
             table_src(i, tu0, tv0, tur1, tvr1);
             const int o = table_off(i);
             rowU[i] = (int)((uint32_t)wrap(tu0 + table_dir(i, su) * o, N) * strideU);
-            colV[i] = wrap(tv0 + table_dir(i, sv) * o, N);
+            colV[i] = (int)((uint32_t)wrap(tv0 + table_dir(i, sv) * o, N) * strideV);
             if (PACK && i % SW1 == 0) { src_uv[2 * (i / SW1)] = tur1; src_uv[2 * (i / SW1) + 1] = tvr1; }
         }
         if (PACK) __syncthreads();  // src_uv
@@ -845,7 +862,7 @@ void sweep_tab_kernel(SweepArgs A) {
         __syncthreads();
         if (tid < NQ * NSRC) {
             // source cell, raytracing.f90:430-439 (QUAD: one copy per quadrant's staging array)
-            const uint32_t g0 = (uint32_t)p0 * strideP + (uint32_t)u0 * strideU + (uint32_t)v0;
+            const uint32_t g0 = (uint32_t)p0 * strideP + (uint32_t)u0 * strideU + (uint32_t)v0 * strideV;
             double nHI = nhi[g0];
             double path = 0.5 * A.dr;
             double cdo = 0.0 + nHI * path;
@@ -969,7 +986,7 @@ void sweep_tab_kernel(SweepArgs A) {
             // (slot 0 holds the wave's highest chunk; with the heating tables the batch would spill)
             // (... and so it does -- 20 to 37 registers -- in the packed kernels, whose lanes carry their own source)
             // ... and in the single-wave multi-sector kernels (R <~ 12), where batching costs 2 - 8 %)
-            const bool all_rates = !HEAT && !PACK && !(QUAD && THREADS == 64) && all_on &&
+            const bool all_rates = (!HEAT || ASORA_HEAT_BATCH) && !PACK && !(QUAD && THREADS == 64) && all_on &&
                                    d0.nchunk - 1 - slot_chunk<NW, SP>(d0, wave, 0) < d0.nchunkA;
 #endif
             if (all_on) {
@@ -1076,9 +1093,19 @@ void sweep_tab_kernel(SweepArgs A) {
 #else
                 const bool add = fire[q];
 #endif
+                // A rate of exactly zero -- behind an optical depth beyond the table's last entry both look-ups clamp to
+                // that entry and phi_in - phi_out == +0 (photorates.f90:140-146) -- changes nothing when added: such lanes
+                // are sent out of range too.  The f64 atomics execute at the memory side (~1.3 TB/s of added bytes
+                // chip-wide, MI355X_MICROARCH.md): with the heating rate as second output they are what bounds the sweep.
+#ifdef ASORA_ADD_ZEROS
                 const int off = (int)(add ? g_c[q] * 8u : BUFFER_OOB);
+                const int off_h = off;
+#else
+                const int off = (int)(add && ph[q] != 0.0 ? g_c[q] * 8u : BUFFER_OOB);
+                const int off_h = (int)(add && (HEAT ? ht[q] : 0.0) != 0.0 ? g_c[q] * 8u : BUFFER_OOB);
+#endif
                 (void)llvm_amdgcn_raw_buffer_atomic_fadd_f64(ph[q], phi_rs, off, 0, 0);
-                if (HEAT) (void)llvm_amdgcn_raw_buffer_atomic_fadd_f64(ht[q], heat_rs, off, 0, 0);
+                if (HEAT) (void)llvm_amdgcn_raw_buffer_atomic_fadd_f64(ht[q], heat_rs, off_h, 0, 0);
             }
             if (!STAG) {  // (STAG: written behind the barrier above; the tables follow at the top of the next plane)
                 phase_barrier<LDS_STAGE>();  // every wave has read the old values it needs
@@ -1154,6 +1181,38 @@ __global__ __launch_bounds__(256) void prep_nhi_kernel(const double *__restrict_
     for (int r = threadIdx.y; r < 32; r += 8) {
         const int k2 = blockIdx.x * 32 + r;
         if (j2 < N && k2 < N) nhiB[slab + (size_t)k2 * N + j2] = tile[threadIdx.x][r];
+    }
+}
+
+// One-layout calls: nhi = ndens*(1-xh) (raytracing.f90:421-422 arithmetic) and the zeroing of up to three output grids
+// (rates, heating rates, column density: the sweep adds straight into them) in ONE streaming pass.  VEC: all pointers
+// 16-byte aligned and the cell count even.
+template <bool VEC>
+__global__ __launch_bounds__(256) void prep_single_kernel(const double *__restrict__ ndens, const double *__restrict__ xh,
+                                                          double *__restrict__ nhi, double *__restrict__ z0,
+                                                          double *__restrict__ z1, double *__restrict__ z2, size_t cells) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if (VEC) {
+        const double2 *n2 = reinterpret_cast<const double2 *>(ndens), *x2 = reinterpret_cast<const double2 *>(xh);
+        double2 *o2 = reinterpret_cast<double2 *>(nhi);
+        const double2 zero = {0.0, 0.0};
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells / 2; i += stride) {
+            const double2 n = n2[i], x = x2[i];
+            double2 v;
+            v.x = n.x * (1.0 - x.x);
+            v.y = n.y * (1.0 - x.y);
+            o2[i] = v;
+            reinterpret_cast<double2 *>(z0)[i] = zero;
+            if (z1) reinterpret_cast<double2 *>(z1)[i] = zero;
+            if (z2) reinterpret_cast<double2 *>(z2)[i] = zero;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
+            nhi[i] = ndens[i] * (1.0 - xh[i]);
+            z0[i] = 0.0;
+            if (z1) z1[i] = 0.0;
+            if (z2) z2[i] = 0.0;
+        }
     }
 }
 

@@ -301,5 +301,6 @@ def last_launch_info():
     _check(_lib.asora_last_launch_info(C.byref(g), C.byref(b), C.byref(l), C.byref(s)))
     return dict(grid=g.value, block=b.value, lds_bytes=l.value, staging={0: "global", 1: "lds", 2: "lds-compact"}[s.value & 3], quad=bool((s.value >> 2) & 3), sectors_per_workgroup=1 << ((s.value >> 2) & 3),
                 sources_per_workgroup=1 << ((s.value >> 4) & 3),
+                single_layout=bool(s.value & 64),
                 table_driven=bool(_lib.asora_last_sweep_is_table_driven()),
                 notice=_lib.asora_last_launch_notice().decode())

@@ -46,9 +46,12 @@ def test_random_small_case_vs_oracle(asora, port_oracle, devlog_oracle, seed):
     for k, v in opts.items():
         asora.set_option(k, v)
     with_heat = seed % 3 == 0
+    # the two grid-layout modes alternate (small cases would all take the one-layout path by default)
+    asora.set_option("single_layout", 1 if (seed // len(VARIANTS)) % 2 == 0 else -1)
     try:
         phi, cdh, heat = run_hip(asora, c, heat=with_heat)
     finally:
+        asora.set_option("single_layout", 0)
         for k in opts:
             asora.set_option(k, {"source_order": 2}.get(k, 0))
     o = cases.run_oracle(port_oracle, c, heat=with_heat, sens=True)

@@ -55,13 +55,24 @@ def load_golden(golden_dir, name):
     return c
 
 
+@pytest.fixture(params=[-1, 1], ids=["two_layouts", "one_layout"])
+def layout(request, asora):
+    """Both grid-layout modes of a call (option "single_layout"): the transposed copies + merge pass of long calls, and
+    the one-layout path short calls take (which these small cases would all take by default)."""
+    asora.set_option("single_layout", request.param)
+    yield request.param
+    asora.set_option("single_layout", 0)
+
+
 @pytest.mark.parametrize("name", list(cases.CASES))
-def test_phi_vs_golden(asora, golden_dir, name):
+def test_phi_vs_golden(asora, golden_dir, name, layout):
     """phi_ion per cell vs the Fortran reference's golden vector (tolerance: see tests/parity.py)."""
     c = load_golden(golden_dir, name)
     phi, cdh, _ = run_hip(asora, c)
+    assert asora.last_launch_info()["single_layout"] == (layout == 1)
     r = compare(phi, c["phi_ion"], sens=c["phi_sens"])
-    record(f"golden {name} (N={c['N']}, R={c['R']:g}, {len(c['flux'])} sources)", r, oracle="reference (golden)")
+    record(f"golden {name} (N={c['N']}, R={c['R']:g}, {len(c['flux'])} sources, {'one layout' if layout == 1 else 'two layouts'})",
+           r, oracle="reference (golden)")
     print(f"\n[{name}] max_rel={r['max_rel']:.3e} n_rel>1e-10={r['n_rel_gt']} frac_floor={r['frac_floor']:.2e} "
           f"n_sens={r['n_sens']} support_equal={r['support_equal']}")
     if name != "lognormal48":  # the one fixture built to be ill-conditioned (tests/parity.py)
@@ -95,7 +106,7 @@ def test_phi_vs_device_log10_oracle(asora, devlog_oracle, name):
 
 
 @pytest.mark.parametrize("name", list(cases.CASES))
-def test_cdh_last_source_vs_golden(asora, golden_dir, name):
+def test_cdh_last_source_vs_golden(asora, golden_dir, name, layout):
     """coldensh_out = outgoing column density of the last source: <= 1e-13 relative wherever the GPU
     visits (octahedron); the Fortran sweeps the whole cube, the GPU leaves zeros outside."""
     c = load_golden(golden_dir, name)
@@ -112,7 +123,7 @@ def test_cdh_last_source_vs_golden(asora, golden_dir, name):
 
 
 @pytest.mark.parametrize("name", ["uniform32_center", "lognormal48", "shadow32", "thick24"])
-def test_heat_vs_golden(asora, golden_dir, name):
+def test_heat_vs_golden(asora, golden_dir, name, layout):
     c = load_golden(golden_dir, name)
     assert bool(c["heat_valid"])
     phi, cdh, heat = run_hip(asora, c, heat=True)
@@ -231,6 +242,31 @@ def test_table_driven_equals_table_free_kernel(asora, golden_dir, name):
         asora.set_option("force_generic", 0)
     assert np.array_equal(cdh_t, cdh_g)
     assert np.array_equal(phi_t, phi_g)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(quad_kernel=-1), dict(quad_kernel=1), dict(quad_kernel=2, src_pack=2),
+                                  dict(wg_threads=1024, compact_staging=1, quad_kernel=-1), dict(lds_stage_limit=1024)])
+@pytest.mark.parametrize("name", ["corner33", "lognormal48", "rcut7p3", "same_cell_sources"])
+def test_one_layout_equals_two_layouts(asora, golden_dir, name, opts):
+    """Option "single_layout": the z-dominant sectors on the [i][j][k] grids (strided in-plane coordinate), rates added
+    straight into the caller's grid.  Same arithmetic per cell, so a single source (one writer per cell) gives
+    bit-identical rates, heating rates and column density in both modes, for every kernel shape."""
+    c = load_golden(golden_dir, name)
+    out = {}
+    for k, v in opts.items():
+        asora.set_option(k, v)
+    try:
+        for mode in (-1, 1):
+            asora.set_option("single_layout", mode)
+            out[mode] = run_hip(asora, c, heat=True, num_src=1)
+            assert asora.last_launch_info()["single_layout"] == (mode == 1)
+    finally:
+        asora.set_option("single_layout", 0)
+        for k in opts:
+            asora.set_option(k, {"source_order": 2}.get(k, 0))
+    for a, b in zip(out[-1], out[1]):
+        assert np.array_equal(a, b)
+    assert (out[1][0] != 0).sum() > 0 and (out[1][2] != 0).sum() > 0
 
 
 def test_fallback_kernel_leaves_a_notice(asora, golden_dir):
