@@ -58,6 +58,39 @@ def test_bench_config_vs_oracle(asora, port_oracle, ref_oracle, density):
     assert m.sum() > 1_000_000 and np.array_equal(cdh[m], o["coldensh_out"][m])
 
 
+def test_bench_config_heating_rate_vs_reference(asora, port_oracle, ref_oracle):
+    """The heating output at full size (north_star: per-cell phi_ion / heating accumulation): 256^3 / R = 60, 12
+    clustered sources, both rate grids of asora_do_all_sources_heat against the compiled reference
+    (photorates.f90:118,124), same bounds as the ionisation rate: no cell through the conditioning term.
+    Outside a source's R-sphere the Fortran adds an UNINITIALISED phi_heat_p to the cell (raytracing.f90:518-532,
+    SURVEY.md 3.4 #8), so with overlapping sources its summed heating grid is polluted wherever one source's cube
+    covers another's sphere.  The comparison therefore runs against the port, and the port is first held to the
+    compiled reference on these very inputs one source at a time, inside that source's R-sphere, to 1e-12."""
+    c = bench_case(12, "clustered")
+    phi, cdh, heat = run_hip(asora, c, heat=True)
+    assert asora.last_launch_info()["staging"] == "lds"
+    box = int(np.ceil(c["R"]))
+    o = cases.run_oracle(port_oracle, c, heat=True, sens=True, max_subbox=box, subboxsize=box)
+    kind = "port"
+    if ref_oracle is not None:
+        # the reference, one source at a time, inside that source's R-sphere (where its heating rate is defined)
+        for s in range(0, len(c["flux"]), 3):
+            one = dict(c, pos=c["pos"][s:s + 1], flux=c["flux"][s:s + 1])
+            p1 = cases.run_oracle(port_oracle, one, heat=True, max_subbox=box, subboxsize=box)
+            r1 = cases.run_oracle(ref_oracle, one, heat=True, max_subbox=box, subboxsize=box)
+            m = p1["phi_heat"] != 0
+            assert m.sum() > 100_000 and np.array_equal(p1["phi_ion"] != 0, m)  # (behind tau = 1e4 the rates are exactly 0)
+            assert np.max(np.abs(p1["phi_heat"][m] - r1["phi_heat"][m]) / np.abs(r1["phi_heat"][m])) <= 1e-12
+            assert np.max(np.abs(p1["phi_ion"][m] - r1["phi_ion"][m]) / np.abs(r1["phi_ion"][m])) <= 1e-12
+        kind = "port, held to the compiled reference source by source inside each R-sphere"
+    o["kind"] = kind
+    check_phi("configs[1] 256^3 clustered R=60 + heating output: phi_ion, 12 sources", phi, o, **BOUNDS["bench256_heat"])
+    check_phi("configs[1] 256^3 clustered R=60 + heating output: phi_heat, 12 sources", heat,
+              dict(phi_ion=o["phi_heat"], phi_sens=o["heat_sens"], kind=kind), **BOUNDS["bench256_heat"])
+    # the heating rate is the ionisation rate weighted with the photon's excess energy: same support
+    assert np.array_equal(heat != 0, phi != 0)
+
+
 def test_bench_R100_wide_workgroups_vs_oracle(asora, port_oracle, ref_oracle):
     """R = 100 at 256^3: 94 KB of staged (column density, weight) pairs; the library stages the column
     densities only (47 KB; two 512-thread workgroups per CU for long source lists, 1024 threads for the 4
@@ -358,4 +391,4 @@ def test_integer_and_non_integer_radius_256(asora, port_oracle, ref_oracle):
 # fraction and a factor of 4 on the worst relative error.
 _B = dict(max_sens=0, max_frac_floor=3e-6, max_rel=1e-9)
 BOUNDS = {k: _B for k in ("bench256_uniform", "bench256_clustered", "bench256_R100", "fullbox256", "config0", "eor250",
-                          "stress512_R60", "stress512_R150", "knife_edge")}
+                          "stress512_R60", "stress512_R150", "knife_edge", "bench256_heat")}
