@@ -4,7 +4,7 @@
 set -u
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="--steps 1 --warmup 0 --no-cpu --no-host-api $*"
+ARGS="--steps 1 --warmup 0 --no-cpu --no-host-api --secondary off $*"
 run() { # name counters...
   name=$1; shift
   timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_${name} -- python3 bench.py $ARGS > gpurun_out/pmc_${tag}_${name}.log 2>&1 || { echo "pass $name failed"; tail -3 gpurun_out/pmc_${tag}_${name}.log; return 1; }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The synthetic configurations of SURVEY.md 8(d) through bench.py (one JSON line each): bash profiles/config_table.sh > out.jsonl
-run() { timeout -k 10 300 python -u bench.py --no-cpu --no-host-api --steps 3 --warmup 1 "$@" 2>/dev/null | tail -1 || exit 1; }
+run() { timeout -k 10 300 python -u bench.py --no-cpu --no-host-api --secondary off --steps 3 --warmup 1 "$@" 2>/dev/null | tail -1 || exit 1; }
 for ns in 1000 10000; do for R in 10 30 60; do run --sources $ns --R $R; done; done
 run --xh 1e-4
 run --dr 6.0268e17            # 50 pc / 256: optically thin cells
