@@ -565,10 +565,9 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             if (int rc = alloc_grid(S.cdhA)) return rc;
             if (int rc = alloc_grid(S.cdhB)) return rc;
         }
-        hipLaunchKernelGGL(asora::prep_nhi_kernel, tg, tb, 0, st, S.n_dev, xh_dev, S.nhiA, S.nhiB, N);
+        // (the two rate accumulators are cleared by the same pass)
+        hipLaunchKernelGGL(asora::prep_nhi_kernel, tg, tb, 0, st, S.n_dev, xh_dev, S.nhiA, S.nhiB, S.phiA, S.phiB, N);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemsetAsync(S.phiA, 0, bytes, st));
-        HIP_TRY(hipMemsetAsync(S.phiB, 0, bytes, st));
         if (want_heat) {
             HIP_TRY(hipMemsetAsync(S.heatA, 0, bytes, st));
             HIP_TRY(hipMemsetAsync(S.heatB, 0, bytes, st));

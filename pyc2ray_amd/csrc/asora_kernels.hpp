@@ -1163,7 +1163,11 @@ void sweep_tab_kernel(SweepArgs A) {
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prep_nhi_kernel(const double *__restrict__ ndens,
                                                        const double *__restrict__ xh, double *__restrict__ nhiA,
-                                                       double *__restrict__ nhiB, int N) {
+                                                       double *__restrict__ nhiB, double *__restrict__ zeroA,
+                                                       double *__restrict__ zeroB, int N) {
+    // (zeroA / zeroB: the two rate accumulators, cleared in the same pass -- every cell of either layout is written
+    // exactly once here.  Inputs are read once and the cleared grids are next touched by memory-side atomics:
+    // non-temporal; the neutral density is what the sweep reads next: default policy.)
     __shared__ double tile[32][33];
     const size_t slab = (size_t)blockIdx.z * N * N;
     const int k = blockIdx.x * 32 + threadIdx.x;
@@ -1171,8 +1175,9 @@ __global__ __launch_bounds__(256) void prep_nhi_kernel(const double *__restrict_
         const int j = blockIdx.y * 32 + r;
         if (j < N && k < N) {
             const size_t id = slab + (size_t)j * N + k;
-            const double v = ndens[id] * (1.0 - xh[id]);
+            const double v = __builtin_nontemporal_load(ndens + id) * (1.0 - __builtin_nontemporal_load(xh + id));
             nhiA[id] = v;
+            __builtin_nontemporal_store(0.0, zeroA + id);
             tile[r][threadIdx.x] = v;
         }
     }
@@ -1180,7 +1185,11 @@ __global__ __launch_bounds__(256) void prep_nhi_kernel(const double *__restrict_
     const int j2 = blockIdx.y * 32 + threadIdx.x;
     for (int r = threadIdx.y; r < 32; r += 8) {
         const int k2 = blockIdx.x * 32 + r;
-        if (j2 < N && k2 < N) nhiB[slab + (size_t)k2 * N + j2] = tile[threadIdx.x][r];
+        if (j2 < N && k2 < N) {
+            const size_t id = slab + (size_t)k2 * N + j2;
+            nhiB[id] = tile[threadIdx.x][r];
+            __builtin_nontemporal_store(0.0, zeroB + id);
+        }
     }
 }
 
@@ -1193,18 +1202,18 @@ __global__ __launch_bounds__(256) void prep_single_kernel(const double *__restri
                                                           double *__restrict__ z1, double *__restrict__ z2, size_t cells) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     if (VEC) {
-        const double2 *n2 = reinterpret_cast<const double2 *>(ndens), *x2 = reinterpret_cast<const double2 *>(xh);
-        double2 *o2 = reinterpret_cast<double2 *>(nhi);
-        const double2 zero = {0.0, 0.0};
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d *n2 = reinterpret_cast<const v2d *>(ndens), *x2 = reinterpret_cast<const v2d *>(xh);
+        v2d *o2 = reinterpret_cast<v2d *>(nhi);
+        const v2d zero = {0.0, 0.0};
+        // (inputs are read once and the zeroed grids are next touched by memory-side atomics: non-temporal; the neutral
+        // density is what the sweep reads next: default policy)
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells / 2; i += stride) {
-            const double2 n = n2[i], x = x2[i];
-            double2 v;
-            v.x = n.x * (1.0 - x.x);
-            v.y = n.y * (1.0 - x.y);
-            o2[i] = v;
-            reinterpret_cast<double2 *>(z0)[i] = zero;
-            if (z1) reinterpret_cast<double2 *>(z1)[i] = zero;
-            if (z2) reinterpret_cast<double2 *>(z2)[i] = zero;
+            const v2d n = __builtin_nontemporal_load(n2 + i), x = __builtin_nontemporal_load(x2 + i);
+            o2[i] = n * (1.0 - x);
+            __builtin_nontemporal_store(zero, reinterpret_cast<v2d *>(z0) + i);
+            if (z1) __builtin_nontemporal_store(zero, reinterpret_cast<v2d *>(z1) + i);
+            if (z2) __builtin_nontemporal_store(zero, reinterpret_cast<v2d *>(z2) + i);
         }
     } else {
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
@@ -1225,7 +1234,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict_
     const int j = blockIdx.y * 32 + threadIdx.x;
     for (int r = threadIdx.y; r < 32; r += 8) {
         const int k = blockIdx.x * 32 + r;
-        if (j < N && k < N) tile[r][threadIdx.x] = B[slab + (size_t)k * N + j];
+        if (j < N && k < N) tile[r][threadIdx.x] = __builtin_nontemporal_load(B + slab + (size_t)k * N + j);
     }
     __syncthreads();
     const int k2 = blockIdx.x * 32 + threadIdx.x;
@@ -1233,7 +1242,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict_
         const int j2 = blockIdx.y * 32 + r;
         if (j2 < N && k2 < N) {
             const size_t id = slab + (size_t)j2 * N + k2;
-            out[id] = A[id] + tile[threadIdx.x][r];
+            __builtin_nontemporal_store(__builtin_nontemporal_load(A + id) + tile[threadIdx.x][r], out + id);
         }
     }
 }
