@@ -114,8 +114,11 @@ int asora_global_pass_dev(double dt, const double *ndens_dev, const double *temp
  * bytes that each GPU holds from library load to process end (its per-device address is taken once, in
  * asora_device_init), and the results land in a page-locked buffer made at init: the call itself performs no
  * hipMalloc / hipFree / hipHostMalloc and no allocating library routine.  Mesh sizes above ASORA_NOALLOC_MAX_M1
- * are refused with an error.  All calls on one GPU share that GPU's scratch record (cleared at the start of every
- * call): calls that overlap on one GPU -- different streams or threads -- race on it; serialise them. */
+ * are refused with an error.  All calls on one GPU share that GPU's scratch: it holds a ring of 8 reduction records,
+ * taken in turn and cleared at the start of the call, so up to 8 calls may be in flight on one GPU at a time (other
+ * streams, calls that do not ask for results); a ninth overlapping call races with the first.  The landing buffer of
+ * the results is one per device: calls that ASK for results must not run concurrently from several host threads (the
+ * library's state is process-global and not thread-safe, like the reference's). */
 #define ASORA_NOALLOC_MAX_M1 1024
 int asora_global_pass_dev_noalloc(double dt, const double *ndens_dev, const double *temp_dev, const double *xh_dev,
                                   double *xh_av_dev, double *xh_intermed_dev, const double *phi_ion_dev,

@@ -34,7 +34,15 @@ std::string g_err;
 
 constexpr int MAX_DEVICES = 64;
 void *noalloc_scratch_ptr[MAX_DEVICES] = {nullptr};  // device address of asora_noalloc_scratch on each device
-static_assert(sizeof(asora::ChemStats) <= ASORA_NOALLOC_SCRATCH_BYTES, "scratch too small");
+// The chemistry kernel's reduction record is taken from a ring of CHEM_RECORDS slots, one per call in turn, so that up
+// to CHEM_RECORDS calls in flight on one GPU (other streams, asynchronous calls) do not share a record.
+constexpr int CHEM_RECORDS = 8, CHEM_RECORD_STRIDE = 32;
+static_assert(sizeof(asora::ChemStats) <= CHEM_RECORD_STRIDE && CHEM_RECORDS * CHEM_RECORD_STRIDE <= ASORA_NOALLOC_SCRATCH_BYTES,
+              "scratch too small");
+std::atomic<unsigned> g_chem_turn{0};
+asora::ChemStats *chem_record(void *ring) {
+    return reinterpret_cast<asora::ChemStats *>(static_cast<char *>(ring) + (g_chem_turn.fetch_add(1) % CHEM_RECORDS) * CHEM_RECORD_STRIDE);
+}
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -122,7 +130,7 @@ struct State {
     double *gscratch = nullptr;
     size_t gscratch_bytes = 0;
     // chemistry pass: reduction results, and grid staging for the host-pointer entry point (lazy)
-    asora::ChemStats *chem_stats = nullptr;
+    void *chem_stats = nullptr;                     // ring of CHEM_RECORDS reduction records (allocating entry point, lazy)
     asora::ChemStats *chem_stats_pinned = nullptr;  // page-locked landing buffer of the no-alloc entry point (made at init)
     double *chem_buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // timing / launch info
@@ -1196,11 +1204,11 @@ int asora_global_pass_dev(double dt, const double *ndens_dev, const double *temp
     if (!ndens_dev || !temp_dev || !xh_dev || !xh_av_dev || !xh_intermed_dev || !phi_ion_dev || !clump_dev)
         return fail(9, "asora_global_pass_dev: null grid pointer");
     ASORA_ON_DEVICE("asora_global_pass_dev");
-    if (!S.chem_stats) HIP_TRY(hipMalloc(&S.chem_stats, sizeof(asora::ChemStats)));
+    if (!S.chem_stats) HIP_TRY(hipMalloc(&S.chem_stats, CHEM_RECORDS * CHEM_RECORD_STRIDE));
     asora::ChemStats h;
     return global_pass_launch(dt, ndens_dev, temp_dev, xh_dev, xh_av_dev, xh_intermed_dev, phi_ion_dev, clump_dev, bh00,
                               albpow, colh0, temph0, abu_c, m1, conv_flag, sum_xh1, sum_xh0, (hipStream_t)stream,
-                              S.chem_stats, &h);
+                              chem_record(S.chem_stats), &h);
 }
 
 int asora_global_pass_dev_noalloc(double dt, const double *ndens_dev, const double *temp_dev, const double *xh_dev,
@@ -1217,11 +1225,11 @@ int asora_global_pass_dev_noalloc(double dt, const double *ndens_dev, const doub
         return fail(9, "asora_global_pass_dev_noalloc: null grid pointer");
     ASORA_ON_DEVICE("asora_global_pass_dev_noalloc");
     // this device's copy of the scratch array, by the address taken at init -- never by the array's name
-    asora::ChemStats *stats = static_cast<asora::ChemStats *>(noalloc_scratch_ptr[S.device]);
-    if (!stats || !S.chem_stats_pinned) return fail(2, "asora_global_pass_dev_noalloc: scratch not set up on device %d", S.device);
+    void *ring = noalloc_scratch_ptr[S.device];
+    if (!ring || !S.chem_stats_pinned) return fail(2, "asora_global_pass_dev_noalloc: scratch not set up on device %d", S.device);
     return global_pass_launch(dt, ndens_dev, temp_dev, xh_dev, xh_av_dev, xh_intermed_dev, phi_ion_dev, clump_dev, bh00,
-                              albpow, colh0, temph0, abu_c, m1, conv_flag, sum_xh1, sum_xh0, (hipStream_t)stream, stats,
-                              S.chem_stats_pinned);
+                              albpow, colh0, temph0, abu_c, m1, conv_flag, sum_xh1, sum_xh0, (hipStream_t)stream,
+                              chem_record(ring), S.chem_stats_pinned);
 }
 
 int asora_global_pass(double dt, const double *ndens, const double *temp, const double *xh, double *xh_av,

@@ -80,3 +80,33 @@ def test_noalloc_entry_point_allocates_nothing_and_runs_without_results():
             assert torch.equal(u[k], w[k]), k
     finally:
         asora.device_close()
+
+
+def test_overlapping_calls_take_their_own_reduction_record():
+    """The chemistry kernel's reduction record comes from a ring of 8 (include/asora_hip.h): a call that asks for its
+    results while another call -- issued without results on another stream, here on a 64x larger mesh, so it is
+    still running -- reduces into the scratch must still get its own counts and sums."""
+    import torch
+    from pyc2ray_amd import libasora as asora
+    big, small = cases.chemistry_case(N=96, seed=5), cases.chemistry_case(N=24, seed=6)
+    keys = ("ndens", "temp", "xh", "xh_av", "xh_intermed", "phi_ion", "clump")
+    chem = lambda c: [c[k] for k in ("bh00", "albpow", "colh0", "temph0", "abu_c")]
+    asora.device_init(96, 8, 0, 1)
+    try:
+        dev = torch.device("cuda", asora.device_index())
+        up = lambda c: {k: torch.from_numpy(np.ascontiguousarray(c[k]).ravel().copy()).to(dev) for k in keys}
+        ptrs = lambda d: [d[k].data_ptr() for k in keys]
+        ref = asora.global_pass_dev(small["dt"], *ptrs(up(small)), *chem(small), small["N"],
+                                    torch.cuda.current_stream(dev).cuda_stream, noalloc=True)
+        side = torch.cuda.Stream(dev)
+        tb, ts = up(big), up(small)
+        torch.cuda.synchronize(dev)
+        for _ in range(3):  # three calls in flight on the side stream, none asks for results
+            assert asora.global_pass_dev(big["dt"], *ptrs(tb), *chem(big), big["N"], side.cuda_stream, want_stats=False,
+                                         noalloc=True) is None
+        got = asora.global_pass_dev(small["dt"], *ptrs(ts), *chem(small), small["N"],
+                                    torch.cuda.current_stream(dev).cuda_stream, noalloc=True)
+        torch.cuda.synchronize(dev)
+        assert got[0] == ref[0] and got[1] == pytest.approx(ref[1], rel=1e-13) and got[2] == pytest.approx(ref[2], rel=1e-13)
+    finally:
+        asora.device_close()
