@@ -303,15 +303,13 @@ void make_geometry(int N, double R, double dr, int q_max, int last_l, int last_r
         auto pos = [&](int a, int b) { return (uint32_t)(rowoff[a + 1] + b + 1); };
         planes.resize(planes.size() + nplanes);
         asora::PlaneInfo *pl = planes.data() + planes.size() - nplanes;
-        pl[0] = {pos(0, 0), 0, (uint32_t)entries, 0, 0.0};
+        pl[0] = {pos(0, 0), 0, (uint32_t)entries};
         for (int n = 1; n <= nmaxmax; n++) {
             const int cut = q_max - n;
             const int H = std::min(std::min(n, LU), cut) + 1, W = std::min(std::min(n, LV), cut) + 1;
             const double dn = (double)n;
             const double P2 = (dr * dn) * (dr * dn);
-            pl[n].off = (uint32_t)meta.size();
-            pl[n].pad = 0;
-            pl[n].alam = (dn - 0.5) / dn;  // raytracing.f90:683 with |dk| = n
+            pl[n].off = (uint32_t)meta.size();  // (alam = (n - 1/2) / n, raytracing.f90:683, is formed on the device)
             for (int pass = 0; pass < 2; pass++) {
                 for (int a = 0; a < H; a++) {
                     const int bend = std::min(W - 1, cut - a);
@@ -612,7 +610,7 @@ int do_all_sources_impl(double R, double *cdh_out_dev, double sig, double dr, co
             const size_t nq = (size_t)1 << qs, nsrc = (size_t)1 << ss, sw = (size_t)(q ? 2 : 1) * A.wtab * nsrc;
             lds_stage = nsrc * nq * (size_t)A.cw_entries * 2 * sizeof(double);
             lds_stage_c = nsrc * nq * (size_t)((A.cw_entries + 1) & ~1) * sizeof(double);  // column densities only
-            lds_fixed = (size_t)(5 * sw + (sw & 1) + asora::PLANE_INFO_DOUBLES * A.nplanes + (ss ? nsrc : 0)) * sizeof(double) + lds_log;
+            lds_fixed = (size_t)(5 * sw + (sw & 1) + asora::plane_table_doubles(A.nplanes) + (ss ? nsrc : 0)) * sizeof(double) + lds_log;
         };
         for (;;) {
             lds_need(qshift, 0, quad);

@@ -56,12 +56,15 @@ constexpr double SQRT2_CUDA = 1.41421356237;
 // One plane of one geometry variant in the cell tables: cells [off, off+cntA) produce rates
 // (dist2/dr2 <= R2 with the oracle's exact arithmetic), [off+cntA, off+cntT) only propagate cdh.
 // Entry 0 of a variant (the source plane) holds off = staging position of cell (0, 0).
-// alam = (n - 1/2) / n (raytracing.f90:683), the same for every cell of plane n.
+// (alam = (n - 1/2) / n, raytracing.f90:683, the same for every cell of plane n, is formed on the device: cinterp_alam.)
+// 12 bytes per plane: the table is copied into every workgroup's LDS, where a few hundred bytes decide how many
+// workgroups a CU holds (R = 30: 41 640 B with 24-byte entries, three workgroups per CU; 40 748 B, four).
 struct PlaneInfo {
-    uint32_t off, cntA, cntT, pad;
-    double alam;
+    uint32_t off, cntA, cntT;
 };
-constexpr int PLANE_INFO_DOUBLES = sizeof(PlaneInfo) / sizeof(double);
+static_assert(sizeof(PlaneInfo) == 12, "plane table entries are packed");
+// doubles the plane table of n planes occupies in LDS
+__host__ __device__ constexpr int plane_table_doubles(int n) { return (n * (int)sizeof(PlaneInfo) + 7) / 8; }
 
 struct SweepArgs {
     const double *nhiA;  // nHI, [i][j][k]
@@ -738,8 +741,8 @@ void sweep_tab_kernel(SweepArgs A) {
     // the variant's plane table: read through LDS so that stepping to the next plane never touches vmcnt
     PlaneInfo *const planes = reinterpret_cast<PlaneInfo *>(asora_smem + off_du + 5 * SW + (SW & 1));
     // PACK: the 1-based in-plane coordinates (u, v) of the group's sources, for the per-plane interpolation tables
-    int *const src_uv = reinterpret_cast<int *>(asora_smem + off_du + 5 * SW + (SW & 1) + PLANE_INFO_DOUBLES * A.nplanes);
-    const int off_log = off_du + 5 * SW + (SW & 1) + PLANE_INFO_DOUBLES * A.nplanes + (PACK ? NSRC : 0);
+    int *const src_uv = reinterpret_cast<int *>(asora_smem + off_du + 5 * SW + (SW & 1) + plane_table_doubles(A.nplanes));
+    const int off_log = off_du + 5 * SW + (SW & 1) + plane_table_doubles(A.nplanes) + (PACK ? NSRC : 0);
     C.stg.g = LDS_STAGE ? nullptr : reinterpret_cast<double2 *>(A.gscratch) + (size_t)blockIdx.x * (size_t)E;
     C.lg = load_log10_table(A.log10_table, off_log, tid, THREADS);
     // this lane's quadrant and source of the group: staging array, sign sets
@@ -858,7 +861,7 @@ void sweep_tab_kernel(SweepArgs A) {
                 else dv_tab[j] = interp_offsets(o, table_dir(j, sv), c1, alam);
             }
         };
-        fill_offsets(planes[1].alam, 1);
+        fill_offsets(cinterp_alam(1), 1);
         __syncthreads();
         if (tid < NQ * NSRC) {
             // source cell, raytracing.f90:430-439 (QUAD: one copy per quadrant's staging array)
@@ -907,7 +910,7 @@ void sweep_tab_kernel(SweepArgs A) {
             if (STAG && d0.n != plane_prev) {
                 // first phase of a plane: the last writes of the plane before are the other half's and land in this slot;
                 // the first half rebuilds the interpolation tables meanwhile (nobody interpolates the old plane any more)
-                if (!second_half) fill_offsets(planes[d0.n].alam, d0.n, THREADS / 2);
+                if (!second_half) fill_offsets(cinterp_alam(d0.n), d0.n, THREADS / 2);
                 phase_barrier<LDS_STAGE>();
                 plane_prev = d0.n;
             }
@@ -1113,7 +1116,7 @@ void sweep_tab_kernel(SweepArgs A) {
                 for (int q = 0; q < P; q++)
                     if (woff[q] >= 0) C.stg.st((uint32_t)woff[q], cdo[q], wo[q]);
                 if (d1.n != n)  // last phase of this plane: interpolation offsets of the next one
-                    fill_offsets(planes[min(n + 1, A.nplanes - 1)].alam, n + 1);
+                    fill_offsets(cinterp_alam(n + 1), n + 1);
             }
             // New values visible -- to the NEXT PLANE.  Within a plane the next phase takes lower chunks of the sequence:
             // it reads old values at positions below everything this phase writes (A cells read A cells only; inside a
