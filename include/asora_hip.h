@@ -205,6 +205,10 @@ int asora_last_launch_info(int *grid, int *block, int *lds_bytes, int *staging_i
  * default 4, 0: plain hipMemcpy), "lds_pad" (extra LDS per workgroup, occupancy experiments). */
 int asora_set_option(const char *name, long long value);
 
+/* Current value of one of the switches above (a caller that changes one for the length of a call puts it back
+ * afterwards: pyc2ray_amd/evolve.py).  No counterpart in the reference. */
+int asora_get_option(const char *name, long long *value);
+
 /* 1 if the last sweep ran the table-driven kernel, 0 for the table-free one. */
 int asora_last_sweep_is_table_driven(void);
 

@@ -27,15 +27,17 @@ asora_core.device_init(N, 64, 0, 1)
 asora_core.photo_table_to_device(c["thin"], c["thick"])
 temp, clump = np.full((N, N, N), 1e4), np.ones((N, N, N))
 out = {}
-for rep in range(2):
-    hist = []
-    t0 = time.perf_counter()
-    xh_new, phi, _ = evolve3D(1e6 * cases.YEAR, c["dr"], flux, pos.T, True, 0, 0, 0.0, False, None, 0, 1, temp,
-                              c["ndens"], c["xh"], clump, c["thin"], c["thick"], c["minlogtau"], c["dlogtau"], c["R"],
-                              1e-4, c["sig"], *[c[k] for k in ("bh00", "albpow", "colh0", "temph0", "abu_c")],
-                              history=hist, want_coldens=False)
-    dt = time.perf_counter() - t0
-    out = dict(sources=ns, iterations=len(hist), seconds=dt, ms_per_iteration=dt / len(hist) * 1e3,
-               mean_xHII=float(xh_new.mean()))
+# the step's default (cells outside the R-sphere for the last source only), then every cell for every source
+for mode, sweep_unobserved in (("default", False), ("sweep_unobserved", True)):
+    for rep in range(2):
+        hist = []
+        t0 = time.perf_counter()
+        xh_new, phi, _ = evolve3D(1e6 * cases.YEAR, c["dr"], flux, pos.T, True, 0, 0, 0.0, False, None, 0, 1, temp,
+                                  c["ndens"], c["xh"], clump, c["thin"], c["thick"], c["minlogtau"], c["dlogtau"], c["R"],
+                                  1e-4, c["sig"], *[c[k] for k in ("bh00", "albpow", "colh0", "temph0", "abu_c")],
+                                  history=hist, want_coldens=False, sweep_unobserved=sweep_unobserved)
+        dt = time.perf_counter() - t0
+        out[mode] = dict(sources=ns, iterations=len(hist), seconds=dt, ms_per_iteration=dt / len(hist) * 1e3,
+                         mean_xHII=float(xh_new.mean()))
 asora_core.device_close()
 print(json.dumps(out))

@@ -1380,6 +1380,31 @@ int asora_set_option(const char *name, long long value) {
     return 0;
 }
 
+int asora_get_option(const char *name, long long *value) {
+    if (!name || !value) return fail(9, "asora_get_option: null pointer");
+    if (!std::strcmp(name, "force_generic")) *value = S.opt.force_generic;
+    else if (!std::strcmp(name, "max_table_cells")) *value = S.opt.max_table_cells;
+    else if (!std::strcmp(name, "lds_pad")) *value = S.opt.lds_pad;
+    else if (!std::strcmp(name, "lds_stage_limit")) *value = S.opt.lds_stage_limit;
+    else if (!std::strcmp(name, "wg_threads")) *value = S.opt.wg_threads;
+    else if (!std::strcmp(name, "source_order")) *value = S.opt.source_order;
+    else if (!std::strcmp(name, "quad_kernel")) *value = S.opt.quad_kernel;
+    else if (!std::strcmp(name, "quad_max_entries")) *value = S.opt.quad_max_entries;
+    else if (!std::strcmp(name, "oct_max_entries")) *value = S.opt.oct_max_entries;
+    else if (!std::strcmp(name, "stride_residue")) *value = S.opt.stride_residue;
+    else if (!std::strcmp(name, "compact_staging")) *value = S.opt.compact_staging;
+    else if (!std::strcmp(name, "src_pack")) *value = S.opt.src_pack;
+    else if (!std::strcmp(name, "pack_max_lds")) *value = S.opt.pack_max_lds;
+    else if (!std::strcmp(name, "pack_max_entries")) *value = S.opt.pack_max_entries;
+    else if (!std::strcmp(name, "skip_unobserved")) *value = S.opt.skip_unobserved;
+    else if (!std::strcmp(name, "skip_saturated")) *value = S.opt.skip_saturated;
+    else if (!std::strcmp(name, "single_layout")) *value = S.opt.single_layout;
+    else if (!std::strcmp(name, "single_max_visits")) *value = S.opt.single_max_visits;
+    else if (!std::strcmp(name, "copy_threads")) *value = g_copy_threads;
+    else return fail(12, "asora_get_option: unknown option '%s'", name);
+    return 0;
+}
+
 int asora_last_sweep_is_table_driven(void) { return S.rec.last_tab; }
 
 const char *asora_last_launch_notice(void) { return S.rec.notice.c_str(); }

@@ -68,6 +68,7 @@ ABI = {
     "asora_last_sweep_ms": (C.c_int, [C.POINTER(C.c_float)]),
     "asora_last_launch_info": (C.c_int, [C.POINTER(C.c_int)] * 4),
     "asora_set_option": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "asora_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
     "asora_source_order": (C.c_int, [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "asora_last_sweep_is_table_driven": (C.c_int, []),
     "asora_last_launch_notice": (C.c_char_p, []),
@@ -278,6 +279,12 @@ def source_order(pos, N, order=2):
 
 def set_option(name, value):
     _check(_lib.asora_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = C.c_longlong()
+    _check(_lib.asora_get_option(name.encode(), C.byref(v)))
+    return v.value
 
 
 def test_division(num, den):

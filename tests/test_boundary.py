@@ -54,6 +54,23 @@ def test_argument_validation_needs_no_gpu():
         libasora.source_data_to_device(np.zeros(3, dtype=np.int64), np.zeros(1), 1)
 
 
+def test_options_read_back_what_was_set():
+    """asora_get_option returns what asora_set_option stored (host state: no GPU needed); unknown names fail in both."""
+    from pyc2ray_amd import libasora
+    for name, value in [("skip_unobserved", 1), ("single_layout", -1), ("single_max_visits", 1 << 40), ("wg_threads", 512)]:
+        before = libasora.get_option(name)
+        try:
+            libasora.set_option(name, value)
+            assert libasora.get_option(name) == value
+        finally:
+            libasora.set_option(name, before)
+        assert libasora.get_option(name) == before
+    with pytest.raises(RuntimeError, match="unknown option"):
+        libasora.get_option("no_such_switch")
+    with pytest.raises(RuntimeError, match="unknown option"):
+        libasora.set_option("no_such_switch", 1)
+
+
 def test_calls_fail_loudly_without_device():
     from pyc2ray_amd import libasora
     import torch

@@ -114,16 +114,21 @@ def test_temperature_factors_kept_from_cell_to_cell(asora, port_oracle, temperat
     assert np.max(np.abs(whole["xh_intermed"] - xi.ravel())) <= 2e-11
 
 
-@pytest.mark.parametrize("skip_unobserved", [0, 1])
-def test_evolve_step_vs_golden(golden_dir, skip_unobserved):
-    """One full evolve step through pyc2ray_amd.evolve.evolve3D (device-resident loop); also with the
-    skip_unobserved option (cells outside the R-sphere swept for the last source only)."""
+_EVOLVE_CDH = {}
+
+
+@pytest.mark.parametrize("sweep_unobserved", [False, True])
+def test_evolve_step_vs_golden(golden_dir, sweep_unobserved):
+    """One full evolve step through pyc2ray_amd.evolve.evolve3D (device-resident loop).  By default the step sweeps
+    the cells outside the R-sphere for the last source only (library option skip_unobserved for the length of the
+    call); sweep_unobserved=True sweeps them for every source.  Same iterations, same grids, the exported column
+    density bit for bit; the caller's option value is put back."""
     from pyc2ray_amd import asora_core
     from pyc2ray_amd.evolve import evolve3D
     g = np.load(os.path.join(golden_dir, "evolve32.npz"))
     c = cases.evolve_case()
     N = c["N"]
-    asora_core.libasora.set_option("skip_unobserved", skip_unobserved)
+    assert asora_core.libasora.get_option("skip_unobserved") == 0
     asora_core.device_init(N, 8, 0, 1)
     try:
         asora_core.photo_table_to_device(c["thin"], c["thick"])
@@ -131,10 +136,10 @@ def test_evolve_step_vs_golden(golden_dir, skip_unobserved):
         xh_new, phi, cdh = evolve3D(c["dt"], c["dr"], c["flux"], c["pos"].T, True, 0, 0, 0.0, False, None, 0, 1,
                                     c["temp"], c["ndens"], c["xh"], c["clump"], c["thin"], c["thick"], c["minlogtau"],
                                     c["dlogtau"], c["R"], c["convergence_fraction"], c["sig"],
-                                    *[c[k] for k in CHEM_KEYS], history=hist)
+                                    *[c[k] for k in CHEM_KEYS], history=hist, sweep_unobserved=sweep_unobserved)
     finally:
         asora_core.device_close()
-        asora_core.libasora.set_option("skip_unobserved", 0)
+    assert asora_core.libasora.get_option("skip_unobserved") == 0  # as the caller left it
     err = np.max(np.abs(xh_new - g["xh_new"]))
     m = g["phi_ion"] > 0
     rel_phi = np.max(np.abs(phi[m] / g["phi_ion"][m] - 1.0))
@@ -143,7 +148,14 @@ def test_evolve_step_vs_golden(golden_dir, skip_unobserved):
     assert [h["conv_flag"] for h in hist] == list(g["conv_flags"])
     assert err <= 1e-8  # north_star bar; typically ~1e-13
     assert rel_phi <= 1e-8  # phi of the last iteration, computed from an xh_av that differs by ~1e-13
-    assert cdh.shape == (N, N, N) and np.all(np.isfinite(cdh))
+    assert cdh.shape == (N, N, N) and np.all(np.isfinite(cdh)) and cdh.max() > 0
+    # the two modes differ in WHICH sources sweep the unobserved cells, not in any arithmetic: the last source's
+    # column density comes out of the same xh_av (to the ~1e-13 the summed rates of three sources allow)
+    _EVOLVE_CDH[sweep_unobserved] = cdh
+    if len(_EVOLVE_CDH) == 2:
+        a, b = _EVOLVE_CDH[False], _EVOLVE_CDH[True]
+        assert np.array_equal(a > 0, b > 0)
+        assert np.max(np.abs(a - b)) <= 1e-9 * np.max(b)
 
 
 def test_evolve_two_steps_shadow128_vs_oracle(port_oracle):
